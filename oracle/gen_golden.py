@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the *reference* itself.
+
+TEST INFRASTRUCTURE ONLY.  This script imports darksim33/Pyneapple from
+``/root/reference/src`` (read-only mount, survey container only) with two
+in-process stand-ins for the absent ``loguru`` / ``cv2`` modules (SURVEY.md
+Appendix B), runs the reference's own ``CurveFitSolver`` / ``NNLSSolver`` on
+seeded synthetic inputs and stores inputs + outputs as small ``.npz`` fixtures
+under ``tests/golden/``.  Only data is written; no reference source travels.
+
+Run (from any cwd):  python3 oracle/gen_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+SEED = 20260503
+
+
+def _install_shims():
+    class _Noop:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    loguru = types.ModuleType("loguru")
+    loguru.logger = _Noop()
+    sys.modules["loguru"] = loguru
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+    cv2.INTER_CUBIC = 2
+    sys.modules["cv2"] = cv2
+    for name in ("nibabel", "h5py"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+
+
+def _versions():
+    import scipy
+
+    return dict(scipy_version=scipy.__version__, numpy_version=np.__version__)
+
+
+def _pack_curvefit(solver, n_params):
+    prs = solver.pixel_results_
+    popt = np.array([pr.params for pr in prs])  # (n_px, n_free)
+    pcov = np.array(
+        [pr.covariance if pr.covariance is not None else np.full((n_params, n_params), np.nan) for pr in prs]
+    )
+    success = np.array([pr.success for pr in prs])
+    return popt, pcov, success
+
+
+def _noise(rng, clean, sigma):
+    return clean * (1.0 + sigma * rng.standard_normal(clean.shape))
+
+
+def gen_curvefit(name, model, names, truth_ranges, p0, bounds, nb, n_vox, sigmas, rng,
+                 max_iter=250, tol=1e-8, bvalues=None, extra=None, per_voxel=False,
+                 fixed=None, scale=1.0):
+    from pyneapple import CurveFitSolver
+
+    b = np.linspace(0.0, 1200.0, nb) if bvalues is None else np.asarray(bvalues, float)
+    all_names = model._all_param_names
+    truth = np.empty((n_vox, len(all_names)))
+    for j, nm in enumerate(all_names):
+        lo, hi = truth_ranges[nm]
+        truth[:, j] = rng.uniform(lo, hi, n_vox)
+    if extra is not None:
+        extra(truth)
+    clean = np.array([model.forward(b, *truth[i]) for i in range(n_vox)]) * scale
+    sig = np.empty(n_vox)
+    parts = np.array_split(np.arange(n_vox), len(sigmas))
+    for s, idx in zip(sigmas, parts):
+        sig[idx] = s
+    y = clean * (1.0 + sig[:, None] * rng.standard_normal(clean.shape))
+
+    solver = CurveFitSolver(model=model, max_iter=max_iter, tol=tol, p0=p0, bounds=bounds)
+    kw = {}
+    out = dict(bvalues=b, y=y, truth=truth, sigma=sig, max_iter=max_iter, tol=tol,
+               param_names=np.array(model.param_names), all_param_names=np.array(all_names))
+    free_names = list(model.param_names)
+    if per_voxel:
+        # IDEAL-style per-voxel p0 / bounds arrays (n_params, n_px); fitters/ideal.py:182-189
+        p0v = np.array([p0[n] for n in names])[:, None] * (1.0 + 0.2 * rng.uniform(-1, 1, (len(names), n_vox)))
+        lo = np.array([bounds[n][0] for n in names])[:, None]
+        hi = np.array([bounds[n][1] for n in names])[:, None]
+        p0v = np.clip(p0v, lo, hi)
+        lov = np.clip(p0v * 0.5, lo, hi)
+        hiv = np.clip(p0v * 1.5, lo, hi)
+        bad = lov >= hiv
+        lov[bad] = np.broadcast_to(lo, lov.shape)[bad]
+        hiv[bad] = np.broadcast_to(hi, hiv.shape)[bad]
+        kw.update(p0=p0v, bounds=(lov, hiv))
+        out.update(p0_arr=p0v, lo_arr=lov, hi_arr=hiv)
+    if fixed is not None:
+        fx = {k: rng.uniform(*v, n_vox) for k, v in fixed.items()}
+        # make data consistent with the fixed maps
+        for k, v in fx.items():
+            truth[:, all_names.index(k)] = v
+        clean = np.array([model.forward(b, *truth[i]) for i in range(n_vox)]) * scale
+        y = clean * (1.0 + sig[:, None] * rng.standard_normal(clean.shape))
+        out.update(y=y, truth=truth)
+        kw.update(pixel_fixed_params=fx)
+        for k, v in fx.items():
+            out["fixed_" + k] = v
+        free_names = [n for n in free_names if n not in fx]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        solver.fit(b, y, **kw)
+    popt, pcov, success = _pack_curvefit(solver, len(free_names))
+    out.update(popt=popt, pcov=pcov, success=success, free_names=np.array(free_names),
+               p0_names=np.array(names), p0_vals=np.array([p0[n] for n in names], float),
+               lo_vals=np.array([bounds[n][0] for n in names], float),
+               hi_vals=np.array([bounds[n][1] for n in names], float), **_versions())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: n_vox={n_vox} success={success.mean():.3f}")
+
+
+def gen_nnls(name, d_range, n_bins, reg_order, mu, nb, n_vox, rng, max_iter=250, sigma=0.01):
+    from pyneapple import NNLSModel, NNLSSolver, TriExpModel
+
+    b = np.linspace(0.0, 1200.0, nb)
+    tri = TriExpModel()
+    truth = np.column_stack([
+        rng.uniform(0.1, 0.3, n_vox), rng.uniform(0.03, 0.1, n_vox), rng.uniform(0.2, 0.4, n_vox),
+        rng.uniform(3e-3, 8e-3, n_vox), rng.uniform(5e-4, 1.5e-3, n_vox)])
+    clean = np.array([tri.forward(b, *truth[i]) for i in range(n_vox)]) * 1000.0
+    y = _noise(rng, clean, sigma)
+    model = NNLSModel(d_range=d_range, n_bins=n_bins)
+    solver = NNLSSolver(model=model, reg_order=reg_order, mu=mu, max_iter=max_iter)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        solver.fit(b, y)
+    A = solver._build_regularized_basis(b)
+    success = np.array([pr.success for pr in solver.pixel_results_])
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), bvalues=b, y=y, d_range=np.array(d_range), n_bins=n_bins,
+        reg_order=reg_order, mu=mu, max_iter=max_iter, bins=model.bins, basis=model.get_basis(b),
+        reg=solver.get_regularization_matrix(), A_checksum=np.array([A.sum(), (A * A).sum()]),
+        coefficients=solver.params_["coefficients"], residual=solver.diagnostics_["residual"],
+        success=success, **_versions())
+    print(f"{name}: n_vox={n_vox} success={success.mean():.3f} nnz~{(solver.params_['coefficients']>0).sum(1).mean():.1f}")
+
+
+def main():
+    os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF_SRC)
+    _install_shims()
+    os.makedirs(OUT, exist_ok=True)
+    from pyneapple import BiExpModel, MonoExpModel, TriExpModel
+
+    rng = np.random.default_rng(SEED)
+    B16 = [0, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 250, 350, 450, 550, 650]  # tests/test_toolbox.py:18-21 is the analogous 16-pt set
+    B8 = [0, 50, 100, 200, 400, 600, 800, 1000]  # tests/test_solver_curvefit.py:15
+
+    mono_p0 = {"S0": 1000.0, "D": 1e-3}
+    mono_bd = {"S0": (1.0, 5000.0), "D": (1e-5, 0.1)}
+    mono_tr = {"S0": (500, 1500), "D": (5e-4, 3e-3)}
+    gen_curvefit("g1_mono_b16", MonoExpModel(), ["S0", "D"], mono_tr, mono_p0, mono_bd, 16, 128, [0.0, 0.01], rng,
+                 bvalues=np.linspace(0, 1200, 16))
+    gen_curvefit("g1_mono_b8", MonoExpModel(), ["S0", "D"], mono_tr, mono_p0, mono_bd, 8, 128, [0.0, 0.01], rng,
+                 bvalues=B8)
+
+    bi_p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001}
+    bi_bd = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}
+    bi_tr = {"f1": (0.1, 0.4), "D1": (5e-3, 5e-2), "D2": (5e-4, 2e-3)}
+    gen_curvefit("g2_bi_reduced", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0, bi_bd, 24, 192, [0.0, 0.01, 0.05], rng)
+    gen_curvefit("g2_bi_s0", BiExpModel(fit_s0=True), ["f1", "D1", "D2", "S0"], dict(bi_tr, S0=(500, 1500)),
+                 dict(bi_p0, S0=1000.0), dict(bi_bd, S0=(1.0, 5000.0)), 24, 128, [0.0, 0.01], rng)
+    gen_curvefit("g2_bi_full", BiExpModel(fit_reduced=False), ["f1", "D1", "f2", "D2"],
+                 {"f1": (100, 400), "D1": (5e-3, 5e-2), "f2": (500, 900), "D2": (5e-4, 2e-3)},
+                 {"f1": 200.0, "D1": 0.01, "f2": 800.0, "D2": 0.001},
+                 {"f1": (0.0, 2000.0), "D1": (1e-3, 0.1), "f2": (0.0, 2000.0), "D2": (1e-5, 5e-3)},
+                 24, 128, [0.0, 0.01], rng)
+
+    tri_p0 = {"f1": 0.2, "D1": 0.05, "f2": 0.3, "D2": 0.005, "D3": 0.001}
+    tri_bd = {"f1": (0.0, 1.0), "D1": (0.01, 0.5), "f2": (0.0, 1.0), "D2": (2e-3, 0.01), "D3": (1e-5, 2e-3)}
+    tri_tr = {"f1": (0.1, 0.3), "D1": (0.03, 0.1), "f2": (0.2, 0.4), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)}
+    tri_names = ["f1", "D1", "f2", "D2", "D3"]
+    gen_curvefit("g3_tri_reduced", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 384, [0.0, 0.01, 0.03], rng)
+    gen_curvefit("g3_tri_reduced_maxiter4", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 96, [0.01], rng,
+                 max_iter=4)
+    gen_curvefit("g3_tri_s0", TriExpModel(fit_s0=True), tri_names + ["S0"], dict(tri_tr, S0=(500, 1500)),
+                 dict(tri_p0, S0=1000.0), dict(tri_bd, S0=(1.0, 5000.0)), 32, 128, [0.0, 0.01], rng)
+    gen_curvefit("g3_tri_full", TriExpModel(fit_reduced=False), ["f1", "D1", "f2", "D2", "f3", "D3"],
+                 {"f1": (100, 300), "D1": (0.03, 0.1), "f2": (200, 400), "D2": (3e-3, 8e-3), "f3": (300, 700), "D3": (5e-4, 1.5e-3)},
+                 {"f1": 200.0, "D1": 0.05, "f2": 300.0, "D2": 0.005, "f3": 500.0, "D3": 0.001},
+                 {"f1": (0.0, 2000.0), "D1": (0.01, 0.5), "f2": (0.0, 2000.0), "D2": (2e-3, 0.01), "f3": (0.0, 2000.0), "D3": (1e-5, 2e-3)},
+                 32, 128, [0.0, 0.01], rng)
+
+    # G5: per-voxel p0 / bounds arrays (IDEAL-style)
+    gen_curvefit("g5_bi_pervoxel", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0, bi_bd, 24, 128, [0.0, 0.01], rng,
+                 per_voxel=True)
+    gen_curvefit("g5_tri_pervoxel", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 128, [0.0, 0.01], rng,
+                 per_voxel=True)
+
+    # G6: fixed parameters (analytic-Jacobian path, curvefit.py:274-288)
+    gen_curvefit("g6_bi_fixed_D1", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0, bi_bd, 24, 96, [0.0, 0.01], rng,
+                 fixed={"D1": (5e-3, 5e-2)})
+    gen_curvefit("g6_mono_t1_fixed", MonoExpModel(fit_t1=True, repetition_time=3000.0), ["S0", "D", "T1"],
+                 dict(mono_tr, T1=(800, 1600)), dict(mono_p0, T1=1000.0), dict(mono_bd, T1=(100.0, 5000.0)),
+                 16, 96, [0.0, 0.01], rng, fixed={"T1": (800, 1600)})
+
+    # G4: NNLS
+    gen_nnls("g4_nnls_250_r2", (0.0008, 0.5), 250, 2, 0.02, 32, 64, rng)
+    gen_nnls("g4_nnls_250_r1", (0.0008, 0.5), 250, 1, 0.02, 32, 32, rng)
+    gen_nnls("g4_nnls_250_r3", (0.0008, 0.5), 250, 3, 0.02, 32, 32, rng)
+    gen_nnls("g4_nnls_50_r2", (1e-4, 0.1), 50, 2, 0.02, 16, 64, rng)
+    gen_nnls("g4_nnls_50_r0", (1e-4, 0.1), 50, 0, 0.02, 16, 32, rng)
+    gen_nnls("g4_nnls_250_r2_maxiter20", (0.0008, 0.5), 250, 2, 0.02, 32, 32, rng, max_iter=20)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,917 @@
+/*
+ * pnx_oracle_trf.c -- CPU restatement (plain C, fp64, scalar) of the reference's
+ * per-voxel bounded non-linear least-squares path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (pyneapple_amd/, the C-ABI
+ * library) links, loads or calls this file; it is used by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg as the checker /
+ * same-box CPU baseline.
+ *
+ * What it restates (reference = darksim33/Pyneapple @ /root/reference, its
+ * arithmetic lives in SciPy 1.15.3 which the reference pins in pyproject.toml:34-36):
+ *   - src/pyneapple/solvers/curvefit.py:246-317   _fit_single_pixel (failure => p0, NaN cov)
+ *   - src/pyneapple/model_functions/multiexp.py:35-241  forward models, T1 / STEAM factors
+ *   - src/pyneapple/models/{monoexp.py:129-163,biexp.py:159-221,triexp.py:177-247} analytic Jacobians
+ *   - src/pyneapple/models/base.py:145-230   fixed-parameter injection / column slicing
+ *   - scipy/optimize/_minpack_py.py:1000-1055 curve_fit -> least_squares, pcov
+ *   - scipy/optimize/_lsq/least_squares.py:814-828  pre-checks, strictly feasible x0
+ *   - scipy/optimize/_lsq/trf.py:128-394      select_step, trf_bounds
+ *   - scipy/optimize/_lsq/common.py:18-245,440-508,705-717  helpers
+ *   - scipy/optimize/_numdiff.py:13-90,146-163,584-625  2-point finite differences with bounds
+ *
+ * Pinning: checked against golden vectors produced by running the reference itself
+ * (oracle/gen_golden.py -> tests/golden/g[1-6]_*.npz) and against SciPy called the
+ * way the reference calls it (tests/test_oracle_*.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define PNXO_MAXN 8   /* max free parameters */
+#define PNXO_MAXM 128 /* max residuals (b-values) */
+
+enum {
+    PNX_MODEL_MONO = 0,
+    PNX_MODEL_BI_REDUCED = 1,
+    PNX_MODEL_BI_S0 = 2,
+    PNX_MODEL_BI_FULL = 3,
+    PNX_MODEL_TRI_REDUCED = 4,
+    PNX_MODEL_TRI_S0 = 5,
+    PNX_MODEL_TRI_FULL = 6
+};
+
+typedef struct {
+    int model;
+    int t1_mode; /* 0 none, 1 T1 (TR), 2 STEAM (TR+TM) */
+    double tr, tm;
+    int n_all;
+    int n_free;
+    int free_idx[PNXO_MAXN];
+    int m;
+    const double *b;
+    const double *y;
+    double full[PNXO_MAXN]; /* full parameter vector; fixed slots pre-filled */
+} prob_t;
+
+static int model_n_base(int model)
+{
+    switch (model) {
+    case PNX_MODEL_MONO: return 2;
+    case PNX_MODEL_BI_REDUCED: return 3;
+    case PNX_MODEL_BI_S0: return 4;
+    case PNX_MODEL_BI_FULL: return 4;
+    case PNX_MODEL_TRI_REDUCED: return 5;
+    case PNX_MODEL_TRI_S0: return 6;
+    case PNX_MODEL_TRI_FULL: return 6;
+    }
+    return -1;
+}
+
+int pnxo_model_n_all(int model, int t1_mode)
+{
+    int n = model_n_base(model);
+    if (n < 0) return -1;
+    return n + (t1_mode ? 1 : 0);
+}
+
+/* model_functions/multiexp.py:35-241 -- same operation order as the numpy expressions */
+static void model_forward(const prob_t *P, const double *p, double *out)
+{
+    const int m = P->m;
+    const double *b = P->b;
+    for (int i = 0; i < m; ++i) {
+        const double nb = -b[i];
+        double s;
+        switch (P->model) {
+        case PNX_MODEL_MONO:
+            s = p[0] * exp(nb * p[1]);
+            break;
+        case PNX_MODEL_BI_REDUCED:
+            s = p[0] * exp(nb * p[1]) + (1 - p[0]) * exp(nb * p[2]);
+            break;
+        case PNX_MODEL_BI_S0:
+            s = p[3] * (p[0] * exp(nb * p[1]) + (1 - p[0]) * exp(nb * p[2]));
+            break;
+        case PNX_MODEL_BI_FULL:
+            s = p[0] * exp(nb * p[1]) + p[2] * exp(nb * p[3]);
+            break;
+        case PNX_MODEL_TRI_REDUCED:
+            s = p[0] * exp(nb * p[1]) + p[2] * exp(nb * p[3]) + (1 - p[0] - p[2]) * exp(nb * p[4]);
+            break;
+        case PNX_MODEL_TRI_S0:
+            s = p[5] * (p[0] * exp(nb * p[1]) + p[2] * exp(nb * p[3]) + (1 - p[0] - p[2]) * exp(nb * p[4]));
+            break;
+        default: /* TRI_FULL */
+            s = p[0] * exp(nb * p[1]) + p[2] * exp(nb * p[3]) + p[4] * exp(nb * p[5]);
+            break;
+        }
+        out[i] = s;
+    }
+    if (P->t1_mode) {
+        const double T1 = p[P->n_all - 1];
+        const double fac = 1 - exp(-P->tr / T1);
+        for (int i = 0; i < m; ++i) out[i] = out[i] * fac;
+        if (P->t1_mode == 2) {
+            const double fs = exp(-P->tm / T1);
+            for (int i = 0; i < m; ++i) out[i] = out[i] * fs;
+        }
+    }
+}
+
+/* analytic Jacobian, all columns, row-major J[i*n_all + k]; models/{monoexp,biexp,triexp}.py jacobian() */
+static void model_jacobian(const prob_t *P, const double *p, double *J)
+{
+    const int m = P->m, na = P->n_all;
+    const double *b = P->b;
+    for (int i = 0; i < m; ++i) {
+        double *r = J + (size_t)i * na;
+        const double x = b[i];
+        double base;
+        switch (P->model) {
+        case PNX_MODEL_MONO: {
+            double e = exp(-x * p[1]);
+            r[0] = e;
+            r[1] = -x * p[0] * e;
+            base = p[0] * e;
+        } break;
+        case PNX_MODEL_BI_REDUCED: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[2]);
+            r[0] = e1 - e2;
+            r[1] = -x * p[0] * e1;
+            r[2] = -x * (1 - p[0]) * e2;
+            base = p[0] * e1 + (1 - p[0]) * e2;
+        } break;
+        case PNX_MODEL_BI_S0: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[2]), S0 = p[3];
+            r[0] = S0 * (e1 - e2);
+            r[1] = -x * S0 * p[0] * e1;
+            r[2] = -x * S0 * (1 - p[0]) * e2;
+            r[3] = p[0] * e1 + (1 - p[0]) * e2;
+            base = S0 * (p[0] * e1 + (1 - p[0]) * e2);
+        } break;
+        case PNX_MODEL_BI_FULL: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[3]);
+            r[0] = e1;
+            r[1] = -x * p[0] * e1;
+            r[2] = e2;
+            r[3] = -x * p[2] * e2;
+            base = p[0] * e1 + p[2] * e2;
+        } break;
+        case PNX_MODEL_TRI_REDUCED: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[3]), e3 = exp(-x * p[4]);
+            double f3 = 1 - p[0] - p[2];
+            r[0] = e1 - e3;
+            r[1] = -x * p[0] * e1;
+            r[2] = e2 - e3;
+            r[3] = -x * p[2] * e2;
+            r[4] = -x * f3 * e3;
+            base = p[0] * e1 + p[2] * e2 + f3 * e3;
+        } break;
+        case PNX_MODEL_TRI_S0: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[3]), e3 = exp(-x * p[4]);
+            double f3 = 1 - p[0] - p[2], S0 = p[5];
+            r[0] = S0 * (e1 - e3);
+            r[1] = -x * S0 * p[0] * e1;
+            r[2] = S0 * (e2 - e3);
+            r[3] = -x * S0 * p[2] * e2;
+            r[4] = -x * S0 * f3 * e3;
+            r[5] = p[0] * e1 + p[2] * e2 + f3 * e3;
+            base = S0 * (p[0] * e1 + p[2] * e2 + f3 * e3);
+        } break;
+        default: {
+            double e1 = exp(-x * p[1]), e2 = exp(-x * p[3]), e3 = exp(-x * p[5]);
+            r[0] = e1;
+            r[1] = -x * p[0] * e1;
+            r[2] = e2;
+            r[3] = -x * p[2] * e2;
+            r[4] = e3;
+            r[5] = -x * p[4] * e3;
+            base = p[0] * e1 + p[2] * e2 + p[4] * e3;
+        } break;
+        }
+        if (P->t1_mode) {
+            /* model_functions/multiexp.py:244-302 apply_t1_jacobian */
+            const int nb = na - 1;
+            const double T1 = p[na - 1], TR = P->tr;
+            const double exp_TR = exp(-TR / T1);
+            const double A = 1 - exp_TR;
+            double fac, jt1;
+            if (P->t1_mode == 2) {
+                const double TM = P->tm;
+                const double exp_TM = exp(-TM / T1);
+                fac = A * exp_TM;
+                jt1 = base * exp_TM / (T1 * T1) * (-TR * exp_TR + TM * A);
+            } else {
+                fac = A;
+                jt1 = base * (-exp_TR * TR / (T1 * T1));
+            }
+            for (int k = 0; k < nb; ++k) r[k] = r[k] * fac;
+            r[nb] = jt1;
+        }
+    }
+}
+
+/* residual f = model(x) - y with free params x injected (models/base.py:145-165; _minpack_py.py:536-554) */
+static void fun(prob_t *P, const double *x, double *f)
+{
+    for (int k = 0; k < P->n_free; ++k) P->full[P->free_idx[k]] = x[k];
+    model_forward(P, P->full, f);
+    for (int i = 0; i < P->m; ++i) f[i] = f[i] - P->y[i];
+}
+
+static double vnorm(const double *v, int n)
+{
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+static double vdot(const double *a, const double *b, int n)
+{
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+static int all_finite(const double *v, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (!isfinite(v[i])) return 0;
+    return 1;
+}
+
+/* common.py:400-438 */
+static void find_active_constraints(const double *x, const double *lb, const double *ub, int n, double rtol, int *active)
+{
+    for (int i = 0; i < n; ++i) {
+        active[i] = 0;
+        if (rtol == 0) {
+            if (x[i] <= lb[i]) active[i] = -1;
+            if (x[i] >= ub[i]) active[i] = 1;
+            continue;
+        }
+        double lower_dist = x[i] - lb[i], upper_dist = ub[i] - x[i];
+        double lt = rtol * fmax(1.0, fabs(lb[i])), ut = rtol * fmax(1.0, fabs(ub[i]));
+        if (isfinite(lb[i]) && lower_dist <= fmin(upper_dist, lt)) active[i] = -1;
+        if (isfinite(ub[i]) && upper_dist <= fmin(lower_dist, ut)) active[i] = 1;
+    }
+}
+
+/* common.py:440-464 */
+static void make_strictly_feasible(double *x, const double *lb, const double *ub, int n, double rstep)
+{
+    int active[PNXO_MAXN];
+    find_active_constraints(x, lb, ub, n, rstep, active);
+    for (int i = 0; i < n; ++i) {
+        if (active[i] == -1)
+            x[i] = (rstep == 0) ? nextafter(lb[i], ub[i]) : lb[i] + rstep * fmax(1.0, fabs(lb[i]));
+        else if (active[i] == 1)
+            x[i] = (rstep == 0) ? nextafter(ub[i], lb[i]) : ub[i] - rstep * fmax(1.0, fabs(ub[i]));
+        if (x[i] < lb[i] || x[i] > ub[i]) x[i] = 0.5 * (lb[i] + ub[i]);
+    }
+}
+
+/* common.py:467-508 */
+static void cl_scaling_vector(const double *x, const double *g, const double *lb, const double *ub, int n, double *v, double *dv)
+{
+    for (int i = 0; i < n; ++i) {
+        v[i] = 1.0;
+        dv[i] = 0.0;
+        if (g[i] < 0 && isfinite(ub[i])) {
+            v[i] = ub[i] - x[i];
+            dv[i] = -1;
+        }
+        if (g[i] > 0 && isfinite(lb[i])) {
+            v[i] = x[i] - lb[i];
+            dv[i] = 1;
+        }
+    }
+}
+
+/* common.py:367-397: returns min step, hits[] */
+static double step_size_to_bound(const double *x, const double *s, const double *lb, const double *ub, int n, int *hits)
+{
+    double steps[PNXO_MAXN];
+    double min_step = INFINITY;
+    for (int i = 0; i < n; ++i) {
+        if (s[i] != 0) {
+            double a = (lb[i] - x[i]) / s[i], c = (ub[i] - x[i]) / s[i];
+            steps[i] = fmax(a, c);
+        } else
+            steps[i] = INFINITY;
+        if (steps[i] < min_step) min_step = steps[i];
+    }
+    if (hits)
+        for (int i = 0; i < n; ++i) {
+            int sg = (s[i] > 0) - (s[i] < 0);
+            hits[i] = (steps[i] == min_step) ? sg : 0;
+        }
+    return min_step;
+}
+
+static int in_bounds(const double *x, const double *lb, const double *ub, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (!(x[i] >= lb[i] && x[i] <= ub[i])) return 0;
+    return 1;
+}
+
+/* J is (m x n) row-major. computes J @ s */
+static void matvec(const double *J, int m, int n, const double *s, double *out)
+{
+    for (int i = 0; i < m; ++i) {
+        double a = 0;
+        for (int k = 0; k < n; ++k) a += J[i * n + k] * s[k];
+        out[i] = a;
+    }
+}
+
+/* common.py:335-362 (1-D s) */
+static double evaluate_quadratic(const double *J, int m, int n, const double *g, const double *s, const double *diag)
+{
+    double Js[PNXO_MAXM];
+    matvec(J, m, n, s, Js);
+    double q = vdot(Js, Js, m);
+    for (int k = 0; k < n; ++k) q += s[k] * diag[k] * s[k];
+    double l = vdot(s, g, n);
+    return 0.5 * q + l;
+}
+
+/* common.py:250-300 */
+static void build_quadratic_1d(const double *J, int m, int n, const double *g, const double *s, const double *diag,
+                               const double *s0, double *a, double *b, double *c)
+{
+    double v[PNXO_MAXM], u[PNXO_MAXM];
+    matvec(J, m, n, s, v);
+    double aa = vdot(v, v, m);
+    for (int k = 0; k < n; ++k) aa += s[k] * diag[k] * s[k];
+    aa *= 0.5;
+    double bb = vdot(g, s, n);
+    if (s0) {
+        matvec(J, m, n, s0, u);
+        bb += vdot(u, v, m);
+        double cc = 0.5 * vdot(u, u, m) + vdot(g, s0, n);
+        double t1 = 0, t2 = 0;
+        for (int k = 0; k < n; ++k) {
+            t1 += s0[k] * diag[k] * s[k];
+            t2 += s0[k] * diag[k] * s0[k];
+        }
+        bb += t1;
+        cc += 0.5 * t2;
+        *c = cc;
+    }
+    *a = aa;
+    *b = bb;
+}
+
+/* common.py:303-322; returns t, *y */
+static double minimize_quadratic_1d(double a, double b, double lb, double ub, double c, double *y)
+{
+    double t[3] = {lb, ub, 0};
+    int nt = 2;
+    if (a != 0) {
+        double ext = -0.5 * b / a;
+        if (lb < ext && ext < ub) t[nt++] = ext;
+    }
+    int best = 0;
+    double yb = 0;
+    for (int i = 0; i < nt; ++i) {
+        double yy = t[i] * (a * t[i] + b) + c;
+        if (i == 0 || yy < yb) { /* np.argmin: first minimum */
+            yb = yy;
+            best = i;
+        }
+    }
+    *y = yb;
+    return t[best];
+}
+
+/* common.py:18-54; x within trust region assumed */
+static void intersect_trust_region(const double *x, const double *s, int n, double Delta, double *t_neg, double *t_pos)
+{
+    double a = vdot(s, s, n);
+    double b = vdot(x, s, n);
+    double c = vdot(x, x, n) - Delta * Delta;
+    double d = sqrt(b * b - a * c);
+    double q = -(b + copysign(d, b));
+    double t1 = q / a, t2 = c / q;
+    if (t1 < t2) {
+        *t_neg = t1;
+        *t_pos = t2;
+    } else {
+        *t_neg = t2;
+        *t_pos = t1;
+    }
+}
+
+/* Thin SVD of A (m x n, row-major), m >= n, by one-sided Jacobi (Hestenes).  Returns
+ * s[] descending, V (n x n row-major, columns = right singular vectors) and ut_f = U^T f. */
+static void svd_thin(const double *A, int m, int n, const double *f, double *s, double *V, double *utf)
+{
+    double W[(PNXO_MAXM + PNXO_MAXN) * PNXO_MAXN];
+    memcpy(W, A, sizeof(double) * (size_t)m * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < m; ++i) {
+                    double wp = W[i * n + p], wq = W[i * n + q];
+                    alpha += wp * wp;
+                    beta += wq * wq;
+                    gamma += wp * wq;
+                }
+                if (gamma == 0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                rotated = 1;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < m; ++i) {
+                    double wp = W[i * n + p], wq = W[i * n + q];
+                    W[i * n + p] = c * wp - sn * wq;
+                    W[i * n + q] = sn * wp + c * wq;
+                }
+                for (int i = 0; i < n; ++i) {
+                    double vp = V[i * n + p], vq = V[i * n + q];
+                    V[i * n + p] = c * vp - sn * vq;
+                    V[i * n + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[PNXO_MAXN], uf[PNXO_MAXN];
+    int order[PNXO_MAXN];
+    for (int k = 0; k < n; ++k) {
+        double nn = 0, d = 0;
+        for (int i = 0; i < m; ++i) nn += W[i * n + k] * W[i * n + k];
+        nn = sqrt(nn);
+        if (f) {
+            for (int i = 0; i < m; ++i) d += W[i * n + k] * f[i];
+            uf[k] = nn > 0 ? d / nn : 0.0;
+        }
+        sv[k] = nn;
+        order[k] = k;
+    }
+    for (int i = 1; i < n; ++i) { /* insertion sort, descending */
+        int o = order[i], j = i - 1;
+        while (j >= 0 && sv[order[j]] < sv[o]) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = o;
+    }
+    double Vt[PNXO_MAXN * PNXO_MAXN];
+    memcpy(Vt, V, sizeof(double) * n * n);
+    for (int k = 0; k < n; ++k) {
+        s[k] = sv[order[k]];
+        if (f) utf[k] = uf[order[k]];
+        for (int i = 0; i < n; ++i) V[i * n + k] = Vt[i * n + order[k]];
+    }
+}
+
+/* common.py:57-168 */
+static void phi_and_derivative(double alpha, const double *suf, const double *s, int n, double Delta, double *phi, double *phi_prime)
+{
+    double pn2 = 0, sp = 0;
+    for (int i = 0; i < n; ++i) {
+        double denom = s[i] * s[i] + alpha;
+        double t = suf[i] / denom;
+        pn2 += t * t;
+        sp += suf[i] * suf[i] / (denom * denom * denom);
+    }
+    double p_norm = sqrt(pn2);
+    *phi = p_norm - Delta;
+    *phi_prime = -sp / p_norm;
+}
+
+static double solve_lsq_trust_region(int n, int m, const double *uf, const double *s, const double *V, double Delta,
+                                     double initial_alpha, double *p, int *n_iter)
+{
+    const double EPS = DBL_EPSILON;
+    double suf[PNXO_MAXN], t[PNXO_MAXN];
+    for (int i = 0; i < n; ++i) suf[i] = s[i] * uf[i];
+    int full_rank = 0;
+    if (m >= n) {
+        double threshold = EPS * m * s[0];
+        full_rank = s[n - 1] > threshold;
+    }
+    if (full_rank) {
+        for (int i = 0; i < n; ++i) t[i] = uf[i] / s[i];
+        for (int i = 0; i < n; ++i) {
+            double a = 0;
+            for (int k = 0; k < n; ++k) a += V[i * n + k] * t[k];
+            p[i] = -a;
+        }
+        if (vnorm(p, n) <= Delta) {
+            *n_iter = 0;
+            return 0.0;
+        }
+    }
+    double alpha_upper = vnorm(suf, n) / Delta;
+    double alpha_lower;
+    double phi, phi_prime;
+    if (full_rank) {
+        phi_and_derivative(0.0, suf, s, n, Delta, &phi, &phi_prime);
+        alpha_lower = -phi / phi_prime;
+    } else
+        alpha_lower = 0.0;
+    double alpha;
+    if (!full_rank && initial_alpha == 0)
+        alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    else
+        alpha = initial_alpha;
+    int it;
+    for (it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        phi_and_derivative(alpha, suf, s, n, Delta, &phi, &phi_prime);
+        if (phi < 0) alpha_upper = alpha;
+        double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) {
+            ++it;
+            break;
+        }
+    }
+    /* python: n_iter = it + 1 where `it` is the loop index at break (or last index) */
+    *n_iter = it > 10 ? 10 : it;
+    for (int i = 0; i < n; ++i) t[i] = suf[i] / (s[i] * s[i] + alpha);
+    for (int i = 0; i < n; ++i) {
+        double a = 0;
+        for (int k = 0; k < n; ++k) a += V[i * n + k] * t[k];
+        p[i] = -a;
+    }
+    double sc = Delta / vnorm(p, n);
+    for (int i = 0; i < n; ++i) p[i] *= sc;
+    return alpha;
+}
+
+/* trf.py:128-202.  p, p_h are modified in place like the numpy code.  Outputs step, step_h, predicted reduction. */
+static double select_step(const double *x, const double *J_h, int m, int n, const double *diag_h, const double *g_h,
+                          double *p, double *p_h, const double *d, double Delta, const double *lb, const double *ub,
+                          double theta, double *step, double *step_h)
+{
+    double xp[PNXO_MAXN];
+    for (int i = 0; i < n; ++i) xp[i] = x[i] + p[i];
+    if (in_bounds(xp, lb, ub, n)) {
+        double p_value = evaluate_quadratic(J_h, m, n, g_h, p_h, diag_h);
+        memcpy(step, p, sizeof(double) * n);
+        memcpy(step_h, p_h, sizeof(double) * n);
+        return -p_value;
+    }
+    int hits[PNXO_MAXN];
+    double p_stride = step_size_to_bound(x, p, lb, ub, n, hits);
+    double r_h[PNXO_MAXN], r[PNXO_MAXN], x_on_bound[PNXO_MAXN];
+    for (int i = 0; i < n; ++i) {
+        r_h[i] = p_h[i];
+        if (hits[i]) r_h[i] *= -1;
+        r[i] = d[i] * r_h[i];
+    }
+    for (int i = 0; i < n; ++i) {
+        p[i] *= p_stride;
+        p_h[i] *= p_stride;
+        x_on_bound[i] = x[i] + p[i];
+    }
+    double t_neg, to_tr;
+    intersect_trust_region(p_h, r_h, n, Delta, &t_neg, &to_tr);
+    double to_bound = step_size_to_bound(x_on_bound, r, lb, ub, n, NULL);
+    double r_stride = fmin(to_bound, to_tr);
+    double r_stride_l, r_stride_u;
+    if (r_stride > 0) {
+        r_stride_l = (1 - theta) * p_stride / r_stride;
+        if (r_stride == to_bound)
+            r_stride_u = theta * to_bound;
+        else
+            r_stride_u = to_tr;
+    } else {
+        r_stride_l = 0;
+        r_stride_u = -1;
+    }
+    double r_value;
+    if (r_stride_l <= r_stride_u) {
+        double a, b, c;
+        build_quadratic_1d(J_h, m, n, g_h, r_h, diag_h, p_h, &a, &b, &c);
+        r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, &r_value);
+        for (int i = 0; i < n; ++i) {
+            r_h[i] *= r_stride;
+            r_h[i] += p_h[i];
+            r[i] = r_h[i] * d[i];
+        }
+    } else
+        r_value = INFINITY;
+
+    for (int i = 0; i < n; ++i) {
+        p[i] *= theta;
+        p_h[i] *= theta;
+    }
+    double p_value = evaluate_quadratic(J_h, m, n, g_h, p_h, diag_h);
+
+    double ag_h[PNXO_MAXN], ag[PNXO_MAXN];
+    for (int i = 0; i < n; ++i) {
+        ag_h[i] = -g_h[i];
+        ag[i] = d[i] * ag_h[i];
+    }
+    to_tr = Delta / vnorm(ag_h, n);
+    to_bound = step_size_to_bound(x, ag, lb, ub, n, NULL);
+    double ag_stride;
+    if (to_bound < to_tr)
+        ag_stride = theta * to_bound;
+    else
+        ag_stride = to_tr;
+    double a, b, c_unused = 0, ag_value;
+    build_quadratic_1d(J_h, m, n, g_h, ag_h, diag_h, NULL, &a, &b, &c_unused);
+    ag_stride = minimize_quadratic_1d(a, b, 0, ag_stride, 0, &ag_value);
+    for (int i = 0; i < n; ++i) {
+        ag_h[i] *= ag_stride;
+        ag[i] *= ag_stride;
+    }
+    if (p_value < r_value && p_value < ag_value) {
+        memcpy(step, p, sizeof(double) * n);
+        memcpy(step_h, p_h, sizeof(double) * n);
+        return -p_value;
+    } else if (r_value < p_value && r_value < ag_value) {
+        memcpy(step, r, sizeof(double) * n);
+        memcpy(step_h, r_h, sizeof(double) * n);
+        return -r_value;
+    } else {
+        memcpy(step, ag, sizeof(double) * n);
+        memcpy(step_h, ag_h, sizeof(double) * n);
+        return -ag_value;
+    }
+}
+
+/* _numdiff.py:13-90 ('1-sided', num_steps=1), :146-163, :584-625 */
+static void jac_fd(prob_t *P, const double *x, const double *f0, const double *lb, const double *ub, double *J)
+{
+    const int n = P->n_free, m = P->m;
+    const double rstep = sqrt(DBL_EPSILON);
+    double x1[PNXO_MAXN], f1[PNXO_MAXM];
+    memcpy(x1, x, sizeof(double) * n);
+    for (int i = 0; i < n; ++i) {
+        double sign = (x[i] >= 0) ? 1.0 : -1.0;
+        double h = rstep * sign * fmax(1.0, fabs(x[i]));
+        int unbounded = (lb[i] == -INFINITY && ub[i] == INFINITY);
+        (void)unbounded; /* the numpy code only short-cuts when ALL are unbounded; formulas agree either way */
+        double lower_dist = x[i] - lb[i], upper_dist = ub[i] - x[i];
+        double xx = x[i] + h;
+        int violated = (xx < lb[i]) || (xx > ub[i]);
+        int fitting = fabs(h) <= fmax(lower_dist, upper_dist);
+        if (violated && fitting) h = -h;
+        if (!fitting) {
+            if (upper_dist >= lower_dist)
+                h = upper_dist;
+            else
+                h = -lower_dist;
+        }
+        x1[i] = x[i] + h;
+        double dx = x1[i] - x[i];
+        fun(P, x1, f1);
+        for (int r = 0; r < m; ++r) J[r * n + i] = (f1[r] - f0[r]) / dx;
+        x1[i] = x[i];
+    }
+}
+
+static void jac_analytic(prob_t *P, const double *x, double *J)
+{
+    double Jall[PNXO_MAXM * PNXO_MAXN];
+    const int n = P->n_free, m = P->m, na = P->n_all;
+    for (int k = 0; k < n; ++k) P->full[P->free_idx[k]] = x[k];
+    model_jacobian(P, P->full, Jall);
+    for (int r = 0; r < m; ++r)
+        for (int k = 0; k < n; ++k) J[r * n + k] = Jall[r * na + P->free_idx[k]];
+}
+
+static void compute_jac(prob_t *P, int jac_mode, const double *x, const double *f, const double *lb, const double *ub, double *J)
+{
+    if (jac_mode == 0)
+        jac_fd(P, x, f, lb, ub, J);
+    else
+        jac_analytic(P, x, J);
+}
+
+/* status: 1..4 scipy termination (success), 0 = max_nfev reached, -1 bad bounds / p0, -2 non-finite data */
+static int fit_one(prob_t *P, const double *p0, const double *lb, const double *ub, int max_nfev, double ftol,
+                   double xtol, double gtol, int jac_mode, double *xout, double *pcov, int *nfev_out, double *cost_out,
+                   int *njev_out)
+{
+    const int n = P->n_free, m = P->m;
+    double x[PNXO_MAXN], f[PNXO_MAXM], J[PNXO_MAXM * PNXO_MAXN], g[PNXO_MAXN];
+    *nfev_out = 0;
+    *njev_out = 0;
+    *cost_out = NAN;
+    /* curve_fit: asarray_chkfinite(ydata) (_minpack_py.py:929-930) */
+    if (!all_finite(P->y, m)) return -2;
+    /* least_squares.py:814-821 */
+    for (int i = 0; i < n; ++i)
+        if (!(lb[i] < ub[i])) return -1;
+    if (!in_bounds(p0, lb, ub, n)) return -1;
+    memcpy(x, p0, sizeof(double) * n);
+    make_strictly_feasible(x, lb, ub, n, 1e-10);
+    fun(P, x, f);
+    if (!all_finite(f, m)) return -2;
+    compute_jac(P, jac_mode, x, f, lb, ub, J);
+
+    int nfev = 1, njev = 1;
+    double cost = 0.5 * vdot(f, f, m);
+    for (int k = 0; k < n; ++k) {
+        double a = 0;
+        for (int i = 0; i < m; ++i) a += J[i * n + k] * f[i];
+        g[k] = a;
+    }
+    double v[PNXO_MAXN], dv[PNXO_MAXN], d[PNXO_MAXN], diag_h[PNXO_MAXN], g_h[PNXO_MAXN];
+    cl_scaling_vector(x, g, lb, ub, n, v, dv);
+    double Delta;
+    {
+        double t[PNXO_MAXN];
+        for (int i = 0; i < n; ++i) t[i] = x[i] * 1.0 / sqrt(v[i]);
+        Delta = vnorm(t, n);
+        if (Delta == 0) Delta = 1.0;
+    }
+    if (max_nfev <= 0) max_nfev = n * 100;
+    double alpha = 0.0;
+    int termination_status = -99; /* None */
+    double J_aug[(PNXO_MAXM + PNXO_MAXN) * PNXO_MAXN], f_aug[PNXO_MAXM + PNXO_MAXN];
+    double s[PNXO_MAXN], V[PNXO_MAXN * PNXO_MAXN], uf[PNXO_MAXN];
+    double x_new[PNXO_MAXN], f_new[PNXO_MAXM];
+    double cost_new = cost;
+
+    for (;;) {
+        cl_scaling_vector(x, g, lb, ub, n, v, dv);
+        double g_norm = 0;
+        for (int i = 0; i < n; ++i) g_norm = fmax(g_norm, fabs(g[i] * v[i]));
+        if (g_norm < gtol) termination_status = 1;
+        if (termination_status != -99 || nfev == max_nfev) break;
+
+        for (int i = 0; i < n; ++i) {
+            d[i] = sqrt(v[i]);
+            diag_h[i] = g[i] * dv[i];
+            g_h[i] = d[i] * g[i];
+        }
+        for (int i = 0; i < m; ++i) {
+            f_aug[i] = f[i];
+            for (int k = 0; k < n; ++k) J_aug[i * n + k] = J[i * n + k] * d[k];
+        }
+        for (int i = 0; i < n; ++i) {
+            f_aug[m + i] = 0;
+            for (int k = 0; k < n; ++k) J_aug[(m + i) * n + k] = (i == k) ? sqrt(diag_h[i]) : 0.0;
+        }
+        const double *J_h = J_aug; /* first m rows */
+        svd_thin(J_aug, m + n, n, f_aug, s, V, uf);
+        double theta = fmax(0.995, 1 - g_norm);
+
+        double actual_reduction = -1;
+        while (actual_reduction <= 0 && nfev < max_nfev) {
+            double p_h[PNXO_MAXN], p[PNXO_MAXN], step[PNXO_MAXN], step_h[PNXO_MAXN];
+            int n_iter;
+            alpha = solve_lsq_trust_region(n, m, uf, s, V, Delta, alpha, p_h, &n_iter);
+            for (int i = 0; i < n; ++i) p[i] = d[i] * p_h[i];
+            double predicted_reduction = select_step(x, J_h, m, n, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+            for (int i = 0; i < n; ++i) x_new[i] = x[i] + step[i];
+            make_strictly_feasible(x_new, lb, ub, n, 0.0);
+            fun(P, x_new, f_new);
+            nfev += 1;
+            double step_h_norm = vnorm(step_h, n);
+            if (!all_finite(f_new, m)) {
+                Delta = 0.25 * step_h_norm;
+                continue;
+            }
+            cost_new = 0.5 * vdot(f_new, f_new, m);
+            actual_reduction = cost - cost_new;
+            /* common.py:222-245 update_tr_radius */
+            double ratio;
+            if (predicted_reduction > 0)
+                ratio = actual_reduction / predicted_reduction;
+            else if (predicted_reduction == 0 && actual_reduction == 0)
+                ratio = 1;
+            else
+                ratio = 0;
+            double Delta_new = Delta;
+            if (ratio < 0.25)
+                Delta_new = 0.25 * step_h_norm;
+            else if (ratio > 0.75 && step_h_norm > 0.95 * Delta)
+                Delta_new = Delta * 2.0;
+            double step_norm = vnorm(step, n);
+            /* common.py:705-717 check_termination */
+            {
+                int ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
+                int xtol_ok = step_norm < xtol * (xtol + vnorm(x, n));
+                if (ftol_ok && xtol_ok)
+                    termination_status = 4;
+                else if (ftol_ok)
+                    termination_status = 2;
+                else if (xtol_ok)
+                    termination_status = 3;
+            }
+            if (termination_status != -99) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual_reduction > 0) {
+            memcpy(x, x_new, sizeof(double) * n);
+            memcpy(f, f_new, sizeof(double) * m);
+            cost = cost_new;
+            compute_jac(P, jac_mode, x, f, lb, ub, J);
+            njev += 1;
+            for (int k = 0; k < n; ++k) {
+                double a = 0;
+                for (int i = 0; i < m; ++i) a += J[i * n + k] * f[i];
+                g[k] = a;
+            }
+        }
+    }
+    if (termination_status == -99) termination_status = 0;
+    *nfev_out = nfev;
+    *njev_out = njev;
+    *cost_out = cost;
+    memcpy(xout, x, sizeof(double) * n);
+    if (termination_status <= 0) return 0;
+
+    if (pcov) {
+        /* _minpack_py.py:1036-1066 */
+        double sv[PNXO_MAXN], Vv[PNXO_MAXN * PNXO_MAXN];
+        int bad = 0;
+        if (m >= n) {
+            svd_thin(J, m, n, NULL, sv, Vv, NULL);
+            double threshold = DBL_EPSILON * (m > n ? m : n) * sv[0];
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double a = 0;
+                    for (int k = 0; k < n; ++k)
+                        if (sv[k] > threshold) a += Vv[i * n + k] * Vv[j * n + k] / (sv[k] * sv[k]);
+                    pcov[i * n + j] = a;
+                    if (isnan(a)) bad = 1;
+                }
+        } else
+            bad = 1;
+        if (bad || !(m > n)) {
+            for (int i = 0; i < n * n; ++i) pcov[i] = INFINITY;
+        } else {
+            double s_sq = 2 * cost / (m - n);
+            for (int i = 0; i < n * n; ++i) pcov[i] = pcov[i] * s_sq;
+        }
+    }
+    return termination_status;
+}
+
+/*
+ * Batched driver.  Layouts mirror the C-ABI of the product (include/pnx.h):
+ *   y (n_vox, n_b) row-major; p0/lo/hi (n_free,) shared or (n_free, n_vox) parameter-major;
+ *   fixed_vals (n_fixed,) shared or (n_fixed, n_vox); popt (n_free, n_vox); pcov (n_vox, n_free, n_free).
+ * On failure (status <= 0) popt = p0 and pcov = NaN  (curvefit.py:308-317).
+ */
+int pnxo_curvefit_batch(int model, int t1_mode, double tr, double tm, long n_vox, int n_b, const double *b,
+                        const double *y, int n_free, const int *free_idx, int n_fixed, const int *fixed_idx,
+                        const double *fixed_vals, int fixed_per_voxel, const double *p0, const double *lo,
+                        const double *hi, int per_voxel, int max_nfev, double ftol, double xtol, double gtol,
+                        int jac_mode, double *popt, double *pcov, int8_t *status, int32_t *nfev, double *cost,
+                        int n_threads)
+{
+    const int n_all = pnxo_model_n_all(model, t1_mode);
+    if (n_all < 0 || n_free < 1 || n_free > PNXO_MAXN || n_b < 1 || n_b > PNXO_MAXM) return -1;
+    if (n_free + n_fixed != n_all) return -1;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (long vx = 0; vx < n_vox; ++vx) {
+        prob_t P;
+        memset(&P, 0, sizeof(P));
+        P.model = model;
+        P.t1_mode = t1_mode;
+        P.tr = tr;
+        P.tm = tm;
+        P.n_all = n_all;
+        P.n_free = n_free;
+        P.m = n_b;
+        P.b = b;
+        P.y = y + (size_t)vx * n_b;
+        for (int k = 0; k < n_free; ++k) P.free_idx[k] = free_idx[k];
+        for (int k = 0; k < n_fixed; ++k)
+            P.full[fixed_idx[k]] = fixed_per_voxel ? fixed_vals[(size_t)k * n_vox + vx] : fixed_vals[k];
+        double p0v[PNXO_MAXN], lov[PNXO_MAXN], hiv[PNXO_MAXN], x[PNXO_MAXN], pc[PNXO_MAXN * PNXO_MAXN];
+        for (int k = 0; k < n_free; ++k) {
+            p0v[k] = per_voxel ? p0[(size_t)k * n_vox + vx] : p0[k];
+            lov[k] = per_voxel ? lo[(size_t)k * n_vox + vx] : lo[k];
+            hiv[k] = per_voxel ? hi[(size_t)k * n_vox + vx] : hi[k];
+        }
+        int nf = 0, nj = 0;
+        double c = NAN;
+        int st = fit_one(&P, p0v, lov, hiv, max_nfev, ftol, xtol, gtol, jac_mode, x, pcov ? pc : NULL, &nf, &c, &nj);
+        if (st <= 0) {
+            for (int k = 0; k < n_free; ++k) x[k] = p0v[k];
+            for (int k = 0; k < n_free * n_free; ++k) pc[k] = NAN;
+        }
+        for (int k = 0; k < n_free; ++k) popt[(size_t)k * n_vox + vx] = x[k];
+        if (pcov) memcpy(pcov + (size_t)vx * n_free * n_free, pc, sizeof(double) * n_free * n_free);
+        if (status) status[vx] = (int8_t)st;
+        if (nfev) nfev[vx] = nf;
+        if (cost) cost[vx] = c;
+    }
+    return 0;
+}
