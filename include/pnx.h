@@ -1,0 +1,166 @@
+/*
+ * pnx.h -- C ABI of the MI355X (gfx950) batched per-voxel fitting library (libpnx_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of darksim33/Pyneapple's pixelwise fitter:
+ * everything a solver plugin needs in order to replace
+ *     CurveFitSolver._fit_data / _fit_single_pixel   (src/pyneapple/solvers/curvefit.py:171-317)
+ *     NNLSSolver._fit_data / _fit_single_pixel       (src/pyneapple/solvers/nnls_solver.py:129-210)
+ * i.e. the per-voxel calls into scipy.optimize.curve_fit (method="trf") and scipy.optimize.nnls.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch/numpy types.
+ *   - Every function returns 0 on success or a negative pnx_error; the message of the last
+ *     error of the calling thread is available through pnx_last_error().
+ *   - `mem` says where the *per-voxel* arrays live: PNX_MEM_HOST (library stages H2D/D2H itself,
+ *     synchronous) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
+ *     enqueues work on `stream` and returns; the caller synchronises).  Small shared inputs
+ *     (b-values, shared p0/bounds, basis, regulariser) are ALWAYS host pointers.
+ *   - The caller allocates all outputs.  The library owns only device scratch.
+ *   - Per-voxel numerical failure never produces an error code: it is reported in `status[]`
+ *     with the reference's sentinel outputs (curvefit.py:308-317, nnls_solver.py:201-210).
+ */
+#ifndef PNX_H
+#define PNX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNX_VERSION_MAJOR 0
+#define PNX_VERSION_MINOR 1
+#define PNX_MAX_PARAMS 8  /* max model parameters (free + fixed) */
+#define PNX_MAX_BVALUES 128
+
+/* Forward models: parameter order is the reference's `_all_param_names`
+ * (models/monoexp.py:91-101, biexp.py:103-118, triexp.py:103-121; formulas
+ * model_functions/multiexp.py:35-202). */
+typedef enum pnx_model {
+    PNX_MODEL_MONO = 0,        /* [S0, D]                      S0*exp(-b D)                          */
+    PNX_MODEL_BI_REDUCED = 1,  /* [f1, D1, D2]                 f1 e1 + (1-f1) e2                      */
+    PNX_MODEL_BI_S0 = 2,       /* [f1, D1, D2, S0]             S0 (f1 e1 + (1-f1) e2)                 */
+    PNX_MODEL_BI_FULL = 3,     /* [f1, D1, f2, D2]             f1 e1 + f2 e2                          */
+    PNX_MODEL_TRI_REDUCED = 4, /* [f1, D1, f2, D2, D3]         f1 e1 + f2 e2 + (1-f1-f2) e3           */
+    PNX_MODEL_TRI_S0 = 5,      /* [f1, D1, f2, D2, D3, S0]     S0 (...)                               */
+    PNX_MODEL_TRI_FULL = 6     /* [f1, D1, f2, D2, f3, D3]     f1 e1 + f2 e2 + f3 e3                  */
+} pnx_model;
+
+typedef enum pnx_jac_mode {
+    PNX_JAC_FD = 0,       /* SciPy '2-point' finite differences -- what the reference uses when no
+                             parameter is fixed (curvefit.py:289-293 -> _minpack_py.py:1000-1001) */
+    PNX_JAC_ANALYTIC = 1  /* model.jacobian() -- what the reference uses with fixed parameters
+                             (curvefit.py:274-288) */
+} pnx_jac_mode;
+
+typedef enum pnx_mem { PNX_MEM_HOST = 0, PNX_MEM_DEVICE = 1 } pnx_mem;
+
+typedef enum pnx_error {
+    PNX_OK = 0,
+    PNX_ERR_INVALID = -1,     /* bad argument (shape, enum, NULL) -- the reference raises ValueError */
+    PNX_ERR_UNSUPPORTED = -2, /* combination not built into this library */
+    PNX_ERR_NO_DEVICE = -3,   /* no usable MI355X / HIP runtime error at start-up */
+    PNX_ERR_HIP = -4,         /* HIP runtime error during the call */
+    PNX_ERR_NOMEM = -5
+} pnx_error;
+
+/* Per-voxel status written by pnx_curvefit_batch_f64 (int8):
+ *    1..4  SciPy termination status (gtol / ftol / xtol / ftol+xtol): success
+ *    0     max_nfev reached            -> reference: RuntimeError -> params=p0, cov=NaN, success=False
+ *   -1     p0 outside bounds or lb>=ub -> reference: ValueError   -> same sentinel
+ *   -2     non-finite signal/residual  -> reference: ValueError   -> same sentinel          */
+/* Per-voxel status written by pnx_nnls_batch_f64 (int8):
+ *    1 converged; 0 iteration limit (`iteration == max_iter`) -> zeros, ||y||; -2 non-finite input */
+
+typedef struct pnx_curvefit_opts {
+    int32_t model;                       /* pnx_model */
+    int32_t n_b;                         /* number of b-values (<= PNX_MAX_BVALUES) */
+    int32_t n_free;                      /* free parameters being fitted */
+    int32_t n_fixed;                     /* fixed parameters; n_free + n_fixed == model's parameter count */
+    int32_t free_idx[PNX_MAX_PARAMS];    /* ascending positions of the free parameters in the model's order
+                                            (models/base.py:167-173 _free_indices) */
+    int32_t fixed_idx[PNX_MAX_PARAMS];   /* positions of the fixed parameters */
+    int32_t per_voxel_p0_bounds;         /* 0: p0/lo/hi are (n_free,) shared; 1: (n_free, n_vox) parameter-major
+                                            (utility/validation.py:177-203,248-297; fitters/ideal.py:240-242) */
+    int32_t fixed_per_voxel;             /* 0: fixed is (n_fixed,); 1: (n_fixed, n_vox)  (curvefit.py:161-169) */
+    int32_t max_nfev;                    /* reference's max_iter -> SciPy max_nfev (curvefit.py:303) */
+    int32_t jac_mode;                    /* pnx_jac_mode */
+    double ftol;                         /* reference's tol (curvefit.py:304) */
+    double xtol;                         /* SciPy default 1e-8 */
+    double gtol;                         /* SciPy default 1e-8 */
+} pnx_curvefit_opts;
+
+int pnx_version(void);
+/* Number of visible HIP devices (0 if none); never fails. */
+int pnx_device_count(void);
+/* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
+int pnx_last_error(char *buf, int n);
+/* Number of parameters of a model, or PNX_ERR_INVALID. */
+int pnx_model_n_params(int model);
+
+/*
+ * Batched bounded non-linear least squares, fp64, results matching SciPy 1.15 curve_fit(method="trf").
+ * Replaces: CurveFitSolver._fit_data (curvefit.py:171-244) for all voxels at once.
+ *
+ *   b      (n_b,)                     host
+ *   y      (n_vox, n_b) row-major     host|device    -- fitters/pixelwise.py:91-96 hands exactly this
+ *   p0,lo,hi  (n_free,) host  or (n_free, n_vox) host|device when opts->per_voxel_p0_bounds
+ *   fixed  (n_fixed,) host or (n_fixed, n_vox) host|device when opts->fixed_per_voxel; NULL if n_fixed==0
+ *   popt   (n_free, n_vox)            out, host|device  (curvefit.py:235)
+ *   pcov   (n_vox, n_free, n_free)    out or NULL       (curvefit.py:236-243; NaN on failure)
+ *   status (n_vox) int8, nfev (n_vox) int32, cost (n_vox) = 0.5*sum(res^2): out, each may be NULL
+ */
+int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const double *b, const double *y,
+                           const double *p0, const double *lo, const double *hi, const double *fixed,
+                           double *popt, double *pcov, int8_t *status, int32_t *nfev, double *cost,
+                           int mem, int device, void *stream);
+
+/*
+ * NNLS plan: everything that is shared by all voxels of one fit -- the regularised design matrix
+ * A = [basis; reg] (nnls_solver.py:61-73) -- is uploaded and factored into its Gram form once.
+ *   basis (n_meas, n_bins) row-major host;  reg (n_reg, n_bins) row-major host or NULL (n_reg = 0).
+ */
+typedef struct pnx_nnls_plan pnx_nnls_plan;
+int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
+                         int n_reg, int device);
+int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
+
+/*
+ * Batched NNLS  min ||A x - [y;0]||_2, x >= 0  per voxel, fp64, results matching scipy.optimize.nnls.
+ * Replaces: NNLSSolver._fit_data (nnls_solver.py:129-180) incl. _extend_signal (never materialised).
+ *   y (n_vox, n_meas) in;  coeff (n_vox, n_bins) out;  rnorm (n_vox) out = ||A x - y_ext||_2;
+ *   status (n_vox) int8, iters (n_vox) int32: out, may be NULL.  max_iter: reference's max_iter
+ *   (0 -> 3*n_bins like SciPy).
+ */
+int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
+                       double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
+
+/* One-shot convenience: plan_create + solve + plan_destroy with host pointers. */
+int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
+                       const double *y, int max_iter, double *coeff, double *rnorm, int8_t *status,
+                       int32_t *iters, int device);
+
+/*
+ * Design-matrix builders (model_functions/nnls.py:17-85), host in / host out, computed on the device
+ * in fp64 so that a host language without numpy can build the same matrices.
+ */
+int pnx_nnls_bins(double d_min, double d_max, int n_bins, double *bins);
+int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis, int device);
+int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg);
+
+/*
+ * Residual / Jacobian / normal-equation sweep at given parameters (one pass of the LM inner loop as a
+ * standalone, HBM-streaming kernel): for every voxel reads y (n_b) and params (n_all), writes
+ * cost = 0.5*||r||^2, g = J^T r (n_all) and the upper triangle of J^T J (n_all(n_all+1)/2).
+ * Device pointers only.  T = float (f32) or double (f64).
+ *   y (n_vox, n_b); params (n_all, n_vox); out_cost (n_vox); out_g (n_all, n_vox); out_jtj (n_tri, n_vox)
+ */
+int pnx_sweep_f32(int model, int64_t n_vox, int n_b, const float *b_host, const float *y, const float *params,
+                  float *out_cost, float *out_g, float *out_jtj, int device, void *stream);
+int pnx_sweep_f64(int model, int64_t n_vox, int n_b, const double *b_host, const double *y, const double *params,
+                  double *out_cost, double *out_g, double *out_jtj, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNX_H */

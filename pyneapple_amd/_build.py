@@ -1,0 +1,69 @@
+"""Build libpnx_hip.so (gfx950) in-tree with hipcc.  No GPU needed: hipcc cross-compiles.
+
+    python -m pyneapple_amd._build [--force] [--jobs N]
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libpnx_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
+N_MODELS = 7
+
+
+def _units():
+    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", []), ("pnx_sweep.o", "pnx_sweep.hip", [])]
+    for m in range(N_MODELS):
+        units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}"]))
+    return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
+    d.append(os.path.join(HERE, "..", "include", "pnx.h"))
+    d.append(os.path.abspath(__file__))
+    return d
+
+
+def _compile(unit):
+    obj, src, extra = unit
+    cmd = [HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return obj, r.returncode, (r.stdout + r.stderr)
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+    newest = max(os.path.getmtime(p) for p in _deps())
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    units = _units()
+    jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        for obj, rc, out in ex.map(_compile, units):
+            if verbose or rc:
+                sys.stderr.write(f"[pnx build] {obj}: rc={rc}\n{out}\n")
+            if rc:
+                raise RuntimeError(f"hipcc failed for {obj}")
+    objs = [os.path.join(OBJ, u[0]) for u in units]
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link of libpnx_hip.so failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    j = None
+    if "--jobs" in sys.argv:
+        j = int(sys.argv[sys.argv.index("--jobs") + 1])
+    print(build(force="--force" in sys.argv, jobs=j, verbose=True))

@@ -1,0 +1,171 @@
+"""Array-level front-end of the C ABI: numpy (host staging) or torch-cuda tensors (HBM resident)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CurvefitOpts, JAC_ANALYTIC, JAC_FD, MEM_DEVICE, MEM_HOST, check, load, ptr
+
+MODEL_IDS = {"mono": 0, "bi_reduced": 1, "bi_s0": 2, "bi_full": 3, "tri_reduced": 4, "tri_s0": 5, "tri_full": 6}
+MODEL_PARAM_NAMES = {
+    "mono": ["S0", "D"],
+    "bi_reduced": ["f1", "D1", "D2"],
+    "bi_s0": ["f1", "D1", "D2", "S0"],
+    "bi_full": ["f1", "D1", "f2", "D2"],
+    "tri_reduced": ["f1", "D1", "f2", "D2", "D3"],
+    "tri_s0": ["f1", "D1", "f2", "D2", "D3", "S0"],
+    "tri_full": ["f1", "D1", "f2", "D2", "f3", "D3"],
+}
+
+
+def _is_torch(a):
+    return a is not None and not isinstance(a, np.ndarray) and hasattr(a, "data_ptr")
+
+
+def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, max_nfev=250, ftol=1e-8, xtol=1e-8,
+              gtol=1e-8, jac="fd"):
+    n_all = len(MODEL_PARAM_NAMES[model])
+    fixed_idx = [int(i) for i in fixed_idx]
+    free_idx = [i for i in range(n_all) if i not in fixed_idx]
+    o = CurvefitOpts()
+    o.model = MODEL_IDS[model]
+    o.n_b = int(n_b)
+    o.n_free = len(free_idx)
+    o.n_fixed = len(fixed_idx)
+    for k, i in enumerate(free_idx):
+        o.free_idx[k] = i
+    for k, i in enumerate(fixed_idx):
+        o.fixed_idx[k] = i
+    o.per_voxel_p0_bounds = int(per_voxel)
+    o.fixed_per_voxel = int(fixed_per_voxel)
+    o.max_nfev = int(max_nfev)
+    o.jac_mode = JAC_FD if jac == "fd" else JAC_ANALYTIC
+    o.ftol, o.xtol, o.gtol = float(ftol), float(xtol), float(gtol)
+    return o
+
+
+def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev=250, ftol=1e-8, xtol=1e-8,
+             gtol=1e-8, jac="fd", want_pcov=True, device=0):
+    """Batched bounded NLLS on host (numpy) arrays.  Shapes as in include/pnx.h.
+
+    Returns dict(popt (n_free, n_vox), pcov (n_vox, n_free, n_free) | None, status int8, nfev int32, cost).
+    """
+    _lib.require_device()
+    b = np.ascontiguousarray(b, np.float64)
+    y = np.ascontiguousarray(np.atleast_2d(y), np.float64)
+    n_vox, n_b = y.shape
+    if b.shape != (n_b,):
+        raise ValueError(f"b has shape {b.shape}, expected ({n_b},)")
+    p0 = np.ascontiguousarray(p0, np.float64)
+    lo = np.ascontiguousarray(lo, np.float64)
+    hi = np.ascontiguousarray(hi, np.float64)
+    per_voxel = p0.ndim == 2
+    fv = None
+    fpv = False
+    if len(fixed_idx):
+        fv = np.ascontiguousarray(fixed_vals, np.float64)
+        fpv = fv.ndim == 2
+    o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac)
+    n = o.n_free
+    want = (n, n_vox) if per_voxel else (n,)
+    if p0.shape != want or lo.shape != want or hi.shape != want:
+        raise ValueError(f"p0/lo/hi must have shape {want}")
+    if fv is not None and fv.shape != ((o.n_fixed, n_vox) if fpv else (o.n_fixed,)):
+        raise ValueError("fixed_vals has the wrong shape")
+    popt = np.empty((n, n_vox))
+    pcov = np.empty((n_vox, n, n)) if want_pcov else None
+    status = np.empty(n_vox, np.int8)
+    nfev = np.empty(n_vox, np.int32)
+    cost = np.empty(n_vox)
+    check(load().pnx_curvefit_batch_f64(C.byref(o), n_vox, ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi), ptr(fv),
+                                        ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost), MEM_HOST, device,
+                                        None))
+    return dict(popt=popt, pcov=pcov, status=status, nfev=nfev, cost=cost)
+
+
+def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, device, stream=None):
+    """Enqueue a batched fit on HBM-resident torch tensors (asynchronous; caller synchronises)."""
+    b = np.ascontiguousarray(b, np.float64)
+    check(load().pnx_curvefit_batch_f64(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
+                                        ptr(fixed), ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost),
+                                        MEM_DEVICE, int(device), stream))
+
+
+class NnlsPlan:
+    """Shared part of one NNLS fit: A = [basis; reg] uploaded and reduced to its Gram form once."""
+
+    def __init__(self, basis, reg=None, device=0):
+        _lib.require_device()
+        basis = np.ascontiguousarray(basis, np.float64)
+        if basis.ndim != 2:
+            raise ValueError("basis must be 2-D (n_meas, n_bins)")
+        self.n_meas, self.n_bins = basis.shape
+        n_reg = 0
+        if reg is not None:
+            reg = np.ascontiguousarray(reg, np.float64)
+            if reg.ndim != 2 or reg.shape[1] != self.n_bins:
+                raise ValueError("reg must be (n_reg, n_bins)")
+            n_reg = reg.shape[0]
+        self.device = device
+        self._h = C.c_void_p()
+        check(load().pnx_nnls_plan_create(C.byref(self._h), self.n_meas, self.n_bins, ptr(basis), ptr(reg), n_reg,
+                                          device))
+
+    def solve(self, y, max_iter=250):
+        y = np.ascontiguousarray(np.atleast_2d(y), np.float64)
+        n_vox = y.shape[0]
+        if y.shape[1] != self.n_meas:
+            raise ValueError(f"signal has {y.shape[1]} measurements, basis has {self.n_meas}")
+        coeff = np.empty((n_vox, self.n_bins))
+        rnorm = np.empty(n_vox)
+        status = np.empty(n_vox, np.int8)
+        iters = np.empty(n_vox, np.int32)
+        check(load().pnx_nnls_solve_f64(self._h, n_vox, ptr(y), int(max_iter), ptr(coeff), ptr(rnorm), ptr(status),
+                                        ptr(iters), MEM_HOST, None))
+        return dict(coefficients=coeff, residual=rnorm, status=status, iters=iters)
+
+    def solve_device(self, n_vox, y, max_iter, coeff, rnorm, status, iters, stream=None):
+        check(load().pnx_nnls_solve_f64(self._h, int(n_vox), ptr(y), int(max_iter), ptr(coeff), ptr(rnorm),
+                                        ptr(status), ptr(iters), MEM_DEVICE, stream))
+
+    def close(self):
+        if self._h:
+            load().pnx_nnls_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nnls(basis, reg, y, max_iter=250, device=0):
+    plan = NnlsPlan(basis, reg, device)
+    try:
+        return plan.solve(y, max_iter)
+    finally:
+        plan.close()
+
+
+def nnls_bins(d_min, d_max, n_bins):
+    out = np.empty(int(n_bins))
+    check(load().pnx_nnls_bins(float(d_min), float(d_max), int(n_bins), ptr(out)))
+    return out
+
+
+def nnls_regularization_matrix(n_bins, order, mu=1.0):
+    out = np.empty((int(n_bins), int(n_bins)))
+    check(load().pnx_nnls_regularization_matrix(int(n_bins), int(order), float(mu), ptr(out)))
+    return out
+
+
+def nnls_basis(b, bins, device=0):
+    _lib.require_device()
+    b = np.ascontiguousarray(b, np.float64)
+    bins = np.ascontiguousarray(bins, np.float64)
+    out = np.empty((b.size, bins.size))
+    check(load().pnx_nnls_basis(b.size, ptr(b), bins.size, ptr(bins), ptr(out), device))
+    return out

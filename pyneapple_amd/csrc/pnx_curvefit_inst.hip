@@ -1,0 +1,59 @@
+// pnx_curvefit_inst.hip -- explicit instantiations of the TRF kernel for ONE model (compile with
+// -DPNX_MODEL=<0..6>); one translation unit per model keeps the build parallel.
+#include "pnx_curvefit_kernel.hpp"
+#include "pnx_internal.hpp"
+
+#ifndef PNX_MODEL
+#error "compile with -DPNX_MODEL=<0..6>"
+#endif
+
+namespace pnx {
+
+template <int MODEL, int N, bool FD>
+static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stream) {
+    auto kern = curvefit_kernel<MODEL, N, FD>;
+    const int block = 256;
+    const size_t shmem = sizeof(double) * (kMaxB + (size_t)(block / kWave) * args.n_b * kWave);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, block, shmem);
+    if (e != hipSuccess || occ < 1) return set_error(PNX_ERR_HIP, "occupancy query failed (shmem=%zu): %s", shmem, hipGetErrorString(e));
+    long long want = (args.n_vox + block - 1) / block;
+    long long cap = (long long)occ * device_cus;
+    int grid = (int)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, args);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PNX_ERR_HIP, "curvefit launch: %s", hipGetErrorString(e));
+    return PNX_OK;
+}
+
+template <int MODEL> static int launch_model(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
+    constexpr int NALL = Model<MODEL>::NALL;
+    if (n_free == NALL) {
+        if (jac_mode == PNX_JAC_FD) return launch_one<MODEL, NALL, true>(args, cus, st);
+        return launch_one<MODEL, NALL, false>(args, cus, st);
+    }
+    if constexpr (NALL >= 2) {
+        if (n_free == NALL - 1) {
+            // with fixed parameters the reference always passes the analytic Jacobian (curvefit.py:274-288)
+            return launch_one<MODEL, NALL - 1, false>(args, cus, st);
+        }
+    }
+    return set_error(PNX_ERR_UNSUPPORTED, "model %d with %d free parameters is not built (built: %d and %d)", MODEL,
+                     n_free, NALL, NALL - 1);
+}
+
+}  // namespace pnx
+
+#define PNX_CAT2(a, b) a##b
+#define PNX_CAT(a, b) PNX_CAT2(a, b)
+extern "C" int PNX_CAT(pnx_launch_curvefit_m, PNX_MODEL)(int n_free, int jac_mode, const pnx::CurvefitArgs *args, int cus,
+                                                          void *stream) {
+    return pnx::launch_model<PNX_MODEL>(n_free, jac_mode, *args, cus, (hipStream_t)stream);
+}

@@ -1,0 +1,947 @@
+// pnx_curvefit_kernel.hpp -- batched bounded NLLS (Trust-Region-Reflective) for gfx950, fp64.
+//
+// Hot path replaced: CurveFitSolver._fit_single_pixel (reference src/pyneapple/solvers/curvefit.py:246-317)
+// -> scipy curve_fit(method="trf") -> least_squares -> trf_bounds (scipy/optimize/_lsq/trf.py:205-394),
+// for every voxel of a volume at once.
+//
+// Mapping to the machine (see DESIGN.md for the measurements behind these choices):
+//   * ONE LANE OWNS ONE VOXEL.  All of TRF's per-voxel algebra (n x n SVD, More' root find, reflective
+//     step selection) is scalar work per problem; giving a voxel a whole wavefront would run that part
+//     at 1/64 efficiency.  The wavefront is the unit that shares the b-value table (LDS), the signal
+//     tile (LDS, [row][lane] so every ds_read_b64 is conflict-free) and the work queue.
+//   * PERSISTENT LANES + WORK QUEUE.  Voxels need 5..60 function evaluations; a lane that finishes pulls the
+//     next voxel from a global atomic counter instead of idling until the slowest voxel of its wave is done.
+//     Every lane leaves the loop as soon as the queue is empty, so the grid always drains.
+//   * ONE FUSED "ROW PASS" per trial point: residual, cost, Jacobian row (2-point FD exactly as
+//     scipy/_numdiff.py:584-625, or analytic), J^T f and a Householder QR of J accumulated 8 rows at a time.
+//     The Jacobian never exists in memory; TRF's SVD of the (m+n) x n augmented matrix is taken from the
+//     n x n triangular factor (QR then one-sided Jacobi), which is as accurate as LAPACK's SVD of J_aug.
+//   * The Jacobian at the trial point is computed speculatively together with f(x_new): an accepted step
+//     (the common case) then needs no second pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnx {
+
+constexpr int kWave = 64;
+constexpr int kMaxB = 128;
+constexpr int kMaxP = 8;
+constexpr int kRowBlk = 8;          // rows merged into the QR factor per Householder block step
+constexpr double kEps = 2.220446049250313e-16;
+constexpr double kSqrtEps = 1.4901161193847656e-08;
+
+struct CurvefitArgs {
+    const double *y;      // (n_vox, n_b)
+    const double *p0;     // (N, n_vox) when per_voxel
+    const double *lo;
+    const double *hi;
+    const double *fixed;  // (n_fixed, n_vox) when fixed_per_voxel
+    double *popt;         // (N, n_vox)
+    double *pcov;         // (n_vox, N, N) or null
+    int8_t *status;
+    int32_t *nfev;
+    double *cost;
+    unsigned long long *queue;  // work-queue head, zeroed before launch
+    long long n_vox;
+    int n_b;
+    int per_voxel;
+    int fixed_per_voxel;
+    int max_nfev;
+    int n_fixed;
+    int pad0;
+    double ftol, xtol, gtol;
+    double p0s[kMaxP], los[kMaxP], his[kMaxP], fixeds[kMaxP];
+    int free_idx[kMaxP];
+    int fixed_idx[kMaxP];
+    double b[kMaxB];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Forward models.  Parameter order and operation order follow model_functions/multiexp.py:35-202;
+// analytic Jacobian columns follow models/{monoexp.py:143-148, biexp.py:172-204, triexp.py:190-230}.
+// E[c] = exp(-b * D_c).
+// ---------------------------------------------------------------------------------------------
+template <int MODEL> struct Model;
+
+template <> struct Model<0> {  // mono [S0, D]
+    static constexpr int NALL = 2, NC = 1;
+    __device__ static constexpr int dpos(int c) { return 1; }
+    __device__ static double signal(const double *p, const double *E) { return p[0] * E[0]; }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        r[0] = E[0];
+        r[1] = -x * p[0] * E[0];
+    }
+};
+template <> struct Model<1> {  // bi reduced [f1, D1, D2]
+    static constexpr int NALL = 3, NC = 2;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : 2; }
+    __device__ static double signal(const double *p, const double *E) { return p[0] * E[0] + (1 - p[0]) * E[1]; }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        r[0] = E[0] - E[1];
+        r[1] = -x * p[0] * E[0];
+        r[2] = -x * (1 - p[0]) * E[1];
+    }
+};
+template <> struct Model<2> {  // bi S0 [f1, D1, D2, S0]
+    static constexpr int NALL = 4, NC = 2;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : 2; }
+    __device__ static double signal(const double *p, const double *E) {
+        return p[3] * (p[0] * E[0] + (1 - p[0]) * E[1]);
+    }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        r[0] = p[3] * (E[0] - E[1]);
+        r[1] = -x * p[3] * p[0] * E[0];
+        r[2] = -x * p[3] * (1 - p[0]) * E[1];
+        r[3] = p[0] * E[0] + (1 - p[0]) * E[1];
+    }
+};
+template <> struct Model<3> {  // bi full [f1, D1, f2, D2]
+    static constexpr int NALL = 4, NC = 2;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : 3; }
+    __device__ static double signal(const double *p, const double *E) { return p[0] * E[0] + p[2] * E[1]; }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        r[0] = E[0];
+        r[1] = -x * p[0] * E[0];
+        r[2] = E[1];
+        r[3] = -x * p[2] * E[1];
+    }
+};
+template <> struct Model<4> {  // tri reduced [f1, D1, f2, D2, D3]
+    static constexpr int NALL = 5, NC = 3;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : (c == 1 ? 3 : 4); }
+    __device__ static double signal(const double *p, const double *E) {
+        return p[0] * E[0] + p[2] * E[1] + (1 - p[0] - p[2]) * E[2];
+    }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        const double f3 = 1 - p[0] - p[2];
+        r[0] = E[0] - E[2];
+        r[1] = -x * p[0] * E[0];
+        r[2] = E[1] - E[2];
+        r[3] = -x * p[2] * E[1];
+        r[4] = -x * f3 * E[2];
+    }
+};
+template <> struct Model<5> {  // tri S0 [f1, D1, f2, D2, D3, S0]
+    static constexpr int NALL = 6, NC = 3;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : (c == 1 ? 3 : 4); }
+    __device__ static double signal(const double *p, const double *E) {
+        return p[5] * (p[0] * E[0] + p[2] * E[1] + (1 - p[0] - p[2]) * E[2]);
+    }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        const double f3 = 1 - p[0] - p[2], S0 = p[5];
+        r[0] = S0 * (E[0] - E[2]);
+        r[1] = -x * S0 * p[0] * E[0];
+        r[2] = S0 * (E[1] - E[2]);
+        r[3] = -x * S0 * p[2] * E[1];
+        r[4] = -x * S0 * f3 * E[2];
+        r[5] = p[0] * E[0] + p[2] * E[1] + f3 * E[2];
+    }
+};
+template <> struct Model<6> {  // tri full [f1, D1, f2, D2, f3, D3]
+    static constexpr int NALL = 6, NC = 3;
+    __device__ static constexpr int dpos(int c) { return c == 0 ? 1 : (c == 1 ? 3 : 5); }
+    __device__ static double signal(const double *p, const double *E) {
+        return p[0] * E[0] + p[2] * E[1] + p[4] * E[2];
+    }
+    __device__ static void jac(const double *p, const double *E, double x, double *r) {
+        r[0] = E[0];
+        r[1] = -x * p[0] * E[0];
+        r[2] = E[1];
+        r[3] = -x * p[2] * E[1];
+        r[4] = E[2];
+        r[5] = -x * p[4] * E[2];
+    }
+};
+
+template <int MODEL> __device__ constexpr int comp_of_param(int j) {
+    for (int c = 0; c < Model<MODEL>::NC; ++c)
+        if (Model<MODEL>::dpos(c) == j) return c;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small dense helpers, everything statically indexed (register resident).
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ inline double dotn(const double *a, const double *b) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += a[i] * b[i];
+    return s;
+}
+template <int N> __device__ inline double normn(const double *a) { return sqrt(dotn<N>(a, a)); }
+
+// Merge RB rows (J part in blk[r][0..N), rhs in blk[r][N]) into the upper-triangular factor R | q
+// by Householder reflections acting on [R[k][k]; blk[:,k]].  Afterwards blk is garbage.
+template <int N, int RB> __device__ inline void qr_merge(double (&R)[N][N], double (&q)[N], double (&blk)[RB][N + 1]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double sig = 0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) sig += blk[r][k] * blk[r][k];
+        if (sig > 0) {
+            const double alpha = R[k][k];
+            const double nrm = sqrt(alpha * alpha + sig);
+            const double beta = alpha <= 0 ? nrm : -nrm;
+            const double v0 = alpha - beta;
+            const double inv_v0 = 1.0 / v0;
+            const double tau = -v0 / beta;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) blk[r][k] *= inv_v0;
+            R[k][k] = beta;
+#pragma unroll
+            for (int j = k + 1; j <= N; ++j) {
+                double w = (j < N) ? R[k][j] : q[k];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) w += blk[r][k] * blk[r][j];
+                w *= tau;
+                if (j < N)
+                    R[k][j] -= w;
+                else
+                    q[k] -= w;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) blk[r][j] -= w * blk[r][k];
+            }
+        }
+    }
+}
+
+// One-sided Jacobi SVD of the N x N matrix W (in place: W <- U*diag(s)), V accumulates the right
+// singular vectors (columns).
+template <int N> __device__ inline void jacobi_svd(double (&W)[N][N], double (&V)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    if (N == 1) return;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                double a = 0, b = 0, g = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    a += W[i][p] * W[i][p];
+                    b += W[i][q] * W[i][q];
+                    g += W[i][p] * W[i][q];
+                }
+                if (fabs(g) > 1.0e-16 * sqrt(a * b)) {
+                    rotated = true;
+                    const double zeta = (b - a) / (2.0 * g);
+                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const double wp = W[i][p], wq = W[i][q];
+                        W[i][p] = c * wp - s * wq;
+                        W[i][q] = s * wp + c * wq;
+                        const double vp = V[i][p], vq = V[i][q];
+                        V[i][p] = c * vp - s * vq;
+                        V[i][q] = s * vp + c * vq;
+                    }
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+}
+
+// scipy/optimize/_lsq/common.py:400-464 with rstep = 0 (np.nextafter form)
+__device__ inline double strictly_feasible0(double x, double lb, double ub) {
+    if (x <= lb) x = nextafter(lb, ub);
+    if (x >= ub) x = nextafter(ub, lb);  // numpy applies the lower mask first, then the upper one
+    if (x < lb || x > ub) x = 0.5 * (lb + ub);
+    return x;
+}
+// same with rstep = 1e-10 (least_squares.py:827-828)
+__device__ inline double strictly_feasible_r(double x, double lb, double ub) {
+    const double rstep = 1e-10;
+    const double lower_dist = x - lb, upper_dist = ub - x;
+    const double lt = rstep * fmax(1.0, fabs(lb)), ut = rstep * fmax(1.0, fabs(ub));
+    int active = 0;
+    if (isfinite(lb) && lower_dist <= fmin(upper_dist, lt)) active = -1;
+    if (isfinite(ub) && upper_dist <= fmin(lower_dist, ut)) active = 1;
+    if (active == -1) x = lb + lt;
+    if (active == 1) x = ub - ut;
+    if (x < lb || x > ub) x = 0.5 * (lb + ub);
+    return x;
+}
+
+// scipy/optimize/_lsq/common.py:367-397
+template <int N>
+__device__ inline double step_size_to_bound(const double *x, const double *s, const double *lb, const double *ub,
+                                            int *hits) {
+    double steps[N];
+    double mn = INFINITY;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        steps[i] = (s[i] != 0) ? fmax((lb[i] - x[i]) / s[i], (ub[i] - x[i]) / s[i]) : INFINITY;
+        mn = fmin(mn, steps[i]);
+    }
+    if (hits) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) hits[i] = (steps[i] == mn) ? ((s[i] > 0) - (s[i] < 0)) : 0;
+    }
+    return mn;
+}
+
+// 0.5*||R2 s||^2 + g_h.s  ==  evaluate_quadratic(J_h, g_h, s, diag=diag_h) (common.py:325-362), because
+// R2^T R2 = J_h^T J_h + diag(diag_h).
+template <int N> __device__ inline void rmul(const double (&R)[N][N], const double *s, double *out) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double a = 0;
+#pragma unroll
+        for (int j = i; j < N; ++j) a += R[i][j] * s[j];
+        out[i] = a;
+    }
+}
+
+// common.py:303-322
+__device__ inline double minimize_quadratic_1d(double a, double b, double lb, double ub, double c, double &y) {
+    double tb = lb, yb = lb * (a * lb + b) + c;
+    const double yu = ub * (a * ub + b) + c;
+    if (yu < yb) {
+        yb = yu;
+        tb = ub;
+    }
+    if (a != 0) {
+        const double ext = -0.5 * b / a;
+        if (lb < ext && ext < ub) {
+            const double ye = ext * (a * ext + b) + c;
+            if (ye < yb) {
+                yb = ye;
+                tb = ext;
+            }
+        }
+    }
+    y = yb;
+    return tb;
+}
+
+// common.py:57-168
+template <int N>
+__device__ inline double solve_lsq_trust_region(int m, const double *uf, const double *s, const double (&V)[N][N],
+                                                double smax, double smin, double Delta, double initial_alpha,
+                                                double *p) {
+    double suf[N], t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) suf[i] = s[i] * uf[i];
+    const bool full_rank = (m >= N) && (smin > kEps * m * smax);
+    if (full_rank) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = uf[i] / s[i];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double a = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) a += V[i][k] * t[k];
+            p[i] = -a;
+        }
+        if (normn<N>(p) <= Delta) return 0.0;
+    }
+    double alpha_upper = normn<N>(suf) / Delta;
+    double alpha_lower = 0.0;
+    auto phi_and_derivative = [&](double alpha, double &phi, double &phi_prime) {
+        double pn2 = 0, sp = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double denom = s[i] * s[i] + alpha;
+            const double q = suf[i] / denom;
+            pn2 += q * q;
+            sp += suf[i] * suf[i] / (denom * denom * denom);
+        }
+        const double p_norm = sqrt(pn2);
+        phi = p_norm - Delta;
+        phi_prime = -sp / p_norm;
+    };
+    double phi, phi_prime;
+    if (full_rank) {
+        phi_and_derivative(0.0, phi, phi_prime);
+        alpha_lower = -phi / phi_prime;
+    }
+    double alpha;
+    if (!full_rank && initial_alpha == 0)
+        alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    else
+        alpha = initial_alpha;
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        phi_and_derivative(alpha, phi, phi_prime);
+        if (phi < 0) alpha_upper = alpha;
+        const double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = suf[i] / (s[i] * s[i] + alpha);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double a = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) a += V[i][k] * t[k];
+        p[i] = -a;
+    }
+    const double sc = Delta / normn<N>(p);
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] *= sc;
+    return alpha;
+}
+
+// trf.py:128-202.  Returns predicted reduction; writes step / step_h.
+template <int N>
+__device__ inline double select_step(const double *x, const double (&R2)[N][N], const double *g_h, double *p,
+                                     double *p_h, const double *d, double Delta, const double *lb, const double *ub,
+                                     double theta, double *step, double *step_h) {
+    bool inb = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double xp = x[i] + p[i];
+        inb = inb && (xp >= lb[i]) && (xp <= ub[i]);
+    }
+    double t1[N], t2[N];
+    if (inb) {
+        rmul<N>(R2, p_h, t1);
+        const double p_value = 0.5 * dotn<N>(t1, t1) + dotn<N>(p_h, g_h);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            step[i] = p[i];
+            step_h[i] = p_h[i];
+        }
+        return -p_value;
+    }
+    int hits[N];
+    const double p_stride = step_size_to_bound<N>(x, p, lb, ub, hits);
+    double r_h[N], r[N], xb[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r_h[i] = hits[i] ? -p_h[i] : p_h[i];
+        r[i] = d[i] * r_h[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        p[i] *= p_stride;
+        p_h[i] *= p_stride;
+        xb[i] = x[i] + p[i];
+    }
+    // intersect_trust_region(p_h, r_h, Delta) (common.py:18-54), positive root
+    double to_tr;
+    {
+        const double a = dotn<N>(r_h, r_h), b = dotn<N>(p_h, r_h), c = dotn<N>(p_h, p_h) - Delta * Delta;
+        const double dd = sqrt(b * b - a * c);
+        const double q = -(b + copysign(dd, b));
+        const double ta = q / a, tb = c / q;
+        to_tr = fmax(ta, tb);
+    }
+    double to_bound = step_size_to_bound<N>(xb, r, lb, ub, nullptr);
+    double r_stride = fmin(to_bound, to_tr);
+    double r_stride_l, r_stride_u;
+    if (r_stride > 0) {
+        r_stride_l = (1 - theta) * p_stride / r_stride;
+        r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
+    } else {
+        r_stride_l = 0;
+        r_stride_u = -1;
+    }
+    double r_value;
+    if (r_stride_l <= r_stride_u) {
+        // build_quadratic_1d(J_h, g_h, r_h, s0=p_h, diag=diag_h) (common.py:250-300)
+        rmul<N>(R2, r_h, t1);   // v
+        rmul<N>(R2, p_h, t2);   // u
+        const double a = 0.5 * dotn<N>(t1, t1);
+        const double b = dotn<N>(g_h, r_h) + dotn<N>(t2, t1);
+        const double c = 0.5 * dotn<N>(t2, t2) + dotn<N>(g_h, p_h);
+        r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, r_value);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            r_h[i] = r_h[i] * r_stride + p_h[i];
+            r[i] = r_h[i] * d[i];
+        }
+    } else
+        r_value = INFINITY;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        p[i] *= theta;
+        p_h[i] *= theta;
+    }
+    rmul<N>(R2, p_h, t1);
+    const double p_value = 0.5 * dotn<N>(t1, t1) + dotn<N>(p_h, g_h);
+
+    double ag_h[N], ag[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ag_h[i] = -g_h[i];
+        ag[i] = d[i] * ag_h[i];
+    }
+    to_tr = Delta / normn<N>(ag_h);
+    to_bound = step_size_to_bound<N>(x, ag, lb, ub, nullptr);
+    double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
+    double ag_value;
+    {
+        rmul<N>(R2, ag_h, t1);
+        const double a = 0.5 * dotn<N>(t1, t1);
+        const double b = dotn<N>(g_h, ag_h);
+        ag_stride = minimize_quadratic_1d(a, b, 0.0, ag_stride, 0.0, ag_value);
+    }
+    if (p_value < r_value && p_value < ag_value) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            step[i] = p[i];
+            step_h[i] = p_h[i];
+        }
+        return -p_value;
+    } else if (r_value < p_value && r_value < ag_value) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            step[i] = r[i];
+            step_h[i] = r_h[i];
+        }
+        return -r_value;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            step[i] = ag[i] * ag_stride;
+            step_h[i] = ag_h[i] * ag_stride;
+        }
+        return -ag_value;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel.  Block = WAVES wavefronts; LDS: b-values + per-wave signal tile y[row][lane].
+// ---------------------------------------------------------------------------------------------
+enum LaneState : int { ST_IDLE = 0, ST_INIT = 1, ST_RUN = 2, ST_FINAL = 3 };
+
+template <int MODEL, int N, bool FD>
+__global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
+    using M = Model<MODEL>;
+    constexpr int NALL = M::NALL;
+    constexpr int NC = M::NC;
+    constexpr bool HASFIXED = (N != NALL);
+    static_assert(!(FD && HASFIXED), "finite-difference mode is only built without fixed parameters");
+
+    extern __shared__ double smem[];
+    const int n_b = A.n_b;
+    double *bsh = smem;                                   // [kMaxB]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    double *ysh = smem + kMaxB + (size_t)wave * n_b * kWave;  // [n_b][64]
+    for (int i = threadIdx.x; i < n_b; i += blockDim.x) bsh[i] = A.b[i];
+    __syncthreads();
+
+    // ---- per-lane persistent state
+    int state = ST_IDLE;
+    long long vox = -1;
+    double x[N], lb[N], ub[N], p0v[N];
+    double pfull[NALL];
+    double g[N], R[N][N], qtf[N];          // at the current iterate x
+    double s[N], uf[N], V[N][N], R2[N][N]; // SVD data of the augmented hat-space Jacobian at x
+    double d[N], g_h[N];
+    double smax = 0, smin = 0, theta = 0;
+    double cost = 0, Delta = 0, alpha = 0;
+    int nfev = 0, term = -99;
+    bool needB = false, first = false;
+    // trial point
+    double xn[N], step_h_norm = 0, step_norm = 0, predicted = 0;
+    int final_status = 0;
+    double final_cost = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill
+        if (state == ST_IDLE) {
+            const unsigned long long idx = atomicAdd(A.queue, 1ULL);
+            if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
+            vox = (long long)idx;
+            bool finite = true;
+            const double *yv = A.y + (size_t)vox * n_b;
+            for (int i = 0; i < n_b; ++i) {
+                const double v = yv[i];
+                finite = finite && isfinite(v);
+                ysh[i * kWave + lane] = v;
+            }
+            bool okb = true;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (A.per_voxel) {
+                    p0v[k] = A.p0[(size_t)k * A.n_vox + vox];
+                    lb[k] = A.lo[(size_t)k * A.n_vox + vox];
+                    ub[k] = A.hi[(size_t)k * A.n_vox + vox];
+                } else {
+                    p0v[k] = A.p0s[k];
+                    lb[k] = A.los[k];
+                    ub[k] = A.his[k];
+                }
+                okb = okb && (lb[k] < ub[k]) && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);
+            }
+            if (HASFIXED) {
+#pragma unroll
+                for (int j = 0; j < NALL; ++j) pfull[j] = 0;
+                for (int f = 0; f < A.n_fixed; ++f) {
+                    const double fv = A.fixed_per_voxel ? A.fixed[(size_t)f * A.n_vox + vox] : A.fixeds[f];
+#pragma unroll
+                    for (int j = 0; j < NALL; ++j)
+                        if (A.fixed_idx[f] == j) pfull[j] = fv;
+                }
+            }
+            if (!finite || !okb) {
+                // reference: ValueError inside curve_fit -> params = p0, cov = NaN, success = False
+                const int st = !finite ? -2 : -1;
+#pragma unroll
+                for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = p0v[k];
+                if (A.pcov)
+                    for (int k = 0; k < N * N; ++k) A.pcov[(size_t)vox * N * N + k] = NAN;
+                if (A.status) A.status[vox] = (int8_t)st;
+                if (A.nfev) A.nfev[vox] = 0;
+                if (A.cost) A.cost[vox] = NAN;
+                continue;  // stays IDLE -> next voxel
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) xn[k] = strictly_feasible_r(p0v[k], lb[k], ub[k]);
+            state = ST_INIT;
+            nfev = 0;
+            term = -99;
+            alpha = 0.0;
+            needB = false;
+        } else if (state == ST_RUN) {
+            // -------------------------------------------------------------- phase B: SVD at the current x
+            if (needB) {
+                double v[N], dv[N], diag_h[N];
+                double g_norm = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {  // CL_scaling_vector (common.py:467-508)
+                    v[i] = 1.0;
+                    dv[i] = 0.0;
+                    if (g[i] < 0 && isfinite(ub[i])) {
+                        v[i] = ub[i] - x[i];
+                        dv[i] = -1;
+                    }
+                    if (g[i] > 0 && isfinite(lb[i])) {
+                        v[i] = x[i] - lb[i];
+                        dv[i] = 1;
+                    }
+                    g_norm = fmax(g_norm, fabs(g[i] * v[i]));
+                }
+                if (first) {  // trf.py:232-236
+                    double t = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const double q = x[i] / sqrt(v[i]);
+                        t += q * q;
+                    }
+                    Delta = sqrt(t);
+                    if (Delta == 0) Delta = 1.0;
+                    first = false;
+                }
+                if (g_norm < A.gtol) term = 1;
+                if (term == -99 && nfev != A.max_nfev) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        d[i] = sqrt(v[i]);
+                        diag_h[i] = g[i] * dv[i];
+                        g_h[i] = d[i] * g[i];
+                    }
+                    // QR of [R*D; diag(sqrt(diag_h))] -> R2, q2 ;  J_aug = Q R2 (trf.py:300-306)
+                    double q2[N];
+                    double blk[N][N + 1];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        q2[i] = qtf[i];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            R2[i][j] = (j >= i) ? R[i][j] * d[j] : 0.0;
+                            blk[i][j] = (i == j) ? sqrt(diag_h[i]) : 0.0;
+                        }
+                        blk[i][N] = 0.0;
+                    }
+                    qr_merge<N, N>(R2, q2, blk);
+                    double W[N][N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) W[i][j] = (j >= i) ? R2[i][j] : 0.0;
+                    jacobi_svd<N>(W, V);
+                    smax = 0;
+                    smin = INFINITY;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        double nn = 0, dq = 0;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) {
+                            nn += W[i][k] * W[i][k];
+                            dq += W[i][k] * q2[i];
+                        }
+                        nn = sqrt(nn);
+                        s[k] = nn;
+                        uf[k] = nn > 0 ? dq / nn : 0.0;
+                        smax = fmax(smax, nn);
+                        smin = fmin(smin, nn);
+                    }
+                    theta = fmax(0.995, 1 - g_norm);
+                }
+                needB = false;
+            }
+            if (term != -99 || nfev >= A.max_nfev) {
+                // trf.py:263-272: leave the outer loop
+                final_status = (term == -99) ? 0 : term;
+                final_cost = cost;
+                // the QR factor of J at the final x is in R (x was either never moved or R was swapped in)
+                state = ST_FINAL;
+            } else {
+                // ---------------------------------------------------------- phase C: trial step
+                double p_h[N], p[N], step[N], step_h[N];
+                alpha = solve_lsq_trust_region<N>(n_b, uf, s, V, smax, smin, Delta, alpha, p_h);
+#pragma unroll
+                for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
+                predicted = select_step<N>(x, R2, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+#pragma unroll
+                for (int i = 0; i < N; ++i) xn[i] = strictly_feasible0(x[i] + step[i], lb[i], ub[i]);
+                step_h_norm = normn<N>(step_h);
+                step_norm = normn<N>(step);
+            }
+        }
+
+        if (state == ST_FINAL) {
+            // ---------------------------------------------------------------- outputs
+            const bool ok = final_status > 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = ok ? x[k] : p0v[k];
+            if (A.status) A.status[vox] = (int8_t)final_status;
+            if (A.nfev) A.nfev[vox] = nfev;
+            if (A.cost) A.cost[vox] = final_cost;
+            if (A.pcov) {
+                double *pc = A.pcov + (size_t)vox * N * N;
+                if (!ok) {
+                    for (int k = 0; k < N * N; ++k) pc[k] = NAN;
+                } else {
+                    // _minpack_py.py:1036-1066: pinv(J^T J) from the SVD of J (= SVD of its R factor), * cost/(m-n)
+                    double W[N][N], Vc[N][N], sv[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) W[i][j] = (j >= i) ? R[i][j] : 0.0;
+                    jacobi_svd<N>(W, Vc);
+                    double sm = 0;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        double nn = 0;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) nn += W[i][k] * W[i][k];
+                        sv[k] = sqrt(nn);
+                        sm = fmax(sm, sv[k]);
+                    }
+                    const double thr = kEps * (n_b > N ? n_b : N) * sm;
+                    const bool dof = n_b > N;
+                    const double s_sq = dof ? 2.0 * final_cost / (double)(n_b - N) : 0.0;
+                    bool bad = false;
+                    double out[N][N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            double a = 0;
+#pragma unroll
+                            for (int k = 0; k < N; ++k)
+                                if (sv[k] > thr) a += Vc[i][k] * Vc[j][k] / (sv[k] * sv[k]);
+                            out[i][j] = a;
+                            bad = bad || isnan(a);
+                        }
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) pc[i * N + j] = (bad || !dof) ? INFINITY : out[i][j] * s_sq;
+                }
+            }
+            state = ST_IDLE;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ row pass at xn
+        // residual f = model(xn) - y, cost, speculative Jacobian (FD or analytic), g = J^T f, QR of J
+        double Rn[N][N], qn[N], gn[N], cost_new = 0;
+        bool finite_f = true;
+        {
+            double pe[NALL];  // full parameter vector at the evaluation point
+            if (HASFIXED) {
+#pragma unroll
+                for (int j = 0; j < NALL; ++j) {
+                    pe[j] = pfull[j];
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        if (A.free_idx[k] == j) pe[j] = xn[k];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NALL; ++j) pe[j] = xn[j];
+            }
+            double hpert[N], inv_dx[N];
+            if (FD) {
+                // _numdiff.py:146-163 (_compute_absolute_step) and :13-90 ('1-sided', num_steps = 1)
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const double sign = (xn[k] >= 0) ? 1.0 : -1.0;
+                    double h = kSqrtEps * sign * fmax(1.0, fabs(xn[k]));
+                    const double lower_dist = xn[k] - lb[k], upper_dist = ub[k] - xn[k];
+                    const double xx = xn[k] + h;
+                    const bool violated = (xx < lb[k]) || (xx > ub[k]);
+                    const bool fitting = fabs(h) <= fmax(lower_dist, upper_dist);
+                    if (violated && fitting) h = -h;
+                    if (!fitting) h = (upper_dist >= lower_dist) ? upper_dist : -lower_dist;
+                    const double x1 = xn[k] + h;
+                    hpert[k] = x1;               // perturbed value
+                    inv_dx[k] = 1.0 / (x1 - xn[k]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                qn[i] = 0;
+                gn[i] = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) Rn[i][j] = 0;
+            }
+            for (int i0 = 0; i0 < n_b; i0 += kRowBlk) {
+                double blk[kRowBlk][N + 1];
+#pragma unroll
+                for (int r = 0; r < kRowBlk; ++r) {
+                    const int i = i0 + r;
+                    const bool live = i < n_b;
+                    const int ii = live ? i : 0;
+                    const double bb = bsh[ii];
+                    const double nb = -bb;
+                    const double yi = ysh[ii * kWave + lane];
+                    double E[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
+                    const double r0 = M::signal(pe, E) - yi;
+                    double jr[N];
+                    if (FD) {
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const int c = comp_of_param<MODEL>(k);
+                            double rk;
+                            if (c >= 0) {
+                                double E2[NC];
+#pragma unroll
+                                for (int cc = 0; cc < NC; ++cc) E2[cc] = E[cc];
+                                E2[c] = exp(nb * hpert[k]);
+                                rk = M::signal(pe, E2) - yi;
+                            } else {
+                                double p2[NALL];
+#pragma unroll
+                                for (int j = 0; j < NALL; ++j) p2[j] = pe[j];
+                                p2[k] = hpert[k];
+                                rk = M::signal(p2, E) - yi;
+                            }
+                            jr[k] = (rk - r0) * inv_dx[k];
+                        }
+                    } else {
+                        double ja[NALL];
+                        M::jac(pe, E, bb, ja);
+                        if (HASFIXED) {
+#pragma unroll
+                            for (int k = 0; k < N; ++k) {
+                                jr[k] = 0;
+#pragma unroll
+                                for (int j = 0; j < NALL; ++j)
+                                    if (A.free_idx[k] == j) jr[k] = ja[j];
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < N; ++k) jr[k] = ja[k];
+                        }
+                    }
+                    const double rr = live ? r0 : 0.0;
+                    finite_f = finite_f && isfinite(rr);
+                    cost_new += rr * rr;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const double jk = live ? jr[k] : 0.0;
+                        blk[r][k] = jk;
+                        gn[k] += jk * rr;
+                    }
+                    blk[r][N] = rr;
+                }
+                qr_merge<N, kRowBlk>(Rn, qn, blk);
+            }
+            cost_new *= 0.5;
+        }
+
+        // ------------------------------------------------------------------ phase D: accept / reject
+        if (state == ST_INIT) {
+            if (!finite_f) {
+                // least_squares.py:857-858 "Residuals are not finite in the initial point" -> failure sentinel
+                final_status = -2;
+                final_cost = NAN;
+                nfev = 0;
+                state = ST_FINAL;
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    x[i] = xn[i];
+                    g[i] = gn[i];
+                    qtf[i] = qn[i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) R[i][j] = Rn[i][j];
+                }
+                cost = cost_new;
+                nfev = 1;
+                needB = true;
+                first = true;
+                state = ST_RUN;
+            }
+        } else {  // ST_RUN
+            nfev += 1;
+            bool accept = false;
+            if (!finite_f) {
+                Delta = 0.25 * step_h_norm;  // trf.py:337-339
+            } else {
+                const double actual = cost - cost_new;
+                double ratio;  // update_tr_radius (common.py:222-245)
+                if (predicted > 0)
+                    ratio = actual / predicted;
+                else if (predicted == 0 && actual == 0)
+                    ratio = 1;
+                else
+                    ratio = 0;
+                double Delta_new = Delta;
+                if (ratio < 0.25)
+                    Delta_new = 0.25 * step_h_norm;
+                else if (ratio > 0.75 && step_h_norm > 0.95 * Delta)
+                    Delta_new = Delta * 2.0;
+                // check_termination (common.py:705-717)
+                const bool ftol_ok = (actual < A.ftol * cost) && (ratio > 0.25);
+                const bool xtol_ok = step_norm < A.xtol * (A.xtol + normn<N>(x));
+                if (ftol_ok && xtol_ok)
+                    term = 4;
+                else if (ftol_ok)
+                    term = 2;
+                else if (xtol_ok)
+                    term = 3;
+                if (term == -99) {
+                    alpha *= Delta / Delta_new;
+                    Delta = Delta_new;
+                }
+                accept = actual > 0;
+            }
+            if (accept) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    x[i] = xn[i];
+                    g[i] = gn[i];
+                    qtf[i] = qn[i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) R[i][j] = Rn[i][j];
+                }
+                cost = cost_new;
+                needB = true;  // also evaluates the gtol test at the new x (trf.py:263-266)
+            } else if (term != -99 || nfev >= A.max_nfev) {
+                needB = true;  // scipy re-evaluates g_norm < gtol at the (unchanged) x before leaving (trf.py:263-272)
+            }
+        }
+    }
+}
+
+}  // namespace pnx

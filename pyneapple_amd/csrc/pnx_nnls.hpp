@@ -1,0 +1,31 @@
+// pnx_nnls.hpp -- internal interface of the batched NNLS solver (see pnx_nnls.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnx {
+
+constexpr int kNnlsMaxBins = 256;  // 4 bins per lane
+constexpr int kNnlsMaxMeas = 128;
+
+struct NnlsPlanData {
+    int device = 0;
+    int cus = 0;
+    int n_meas = 0, n_bins = 0, n_reg = 0;
+    double *B = nullptr;      // (n_meas, n_bins) row-major: basis
+    double *RT = nullptr;     // (n_bins, n_reg)  row-major: reg transposed (column j of reg contiguous)
+    double *G = nullptr;      // (n_bins, n_bins): A^T A = B^T B + reg^T reg, fp64
+    double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
+    size_t mglob_stride = 0;  // doubles per wave
+    int n_waves = 0;          // persistent waves the scratch was sized for
+    unsigned long long *queue = nullptr;
+};
+
+int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
+                   int device, int cus);
+void nnls_plan_free(NnlsPlanData *P);
+int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d,
+                      double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis);
+
+}  // namespace pnx
