@@ -67,8 +67,10 @@ typedef enum pnx_error {
 /* Per-voxel status written by pnx_curvefit_batch_f64 (int8):
  *    1..4  SciPy termination status (gtol / ftol / xtol / ftol+xtol): success
  *    0     max_nfev reached            -> reference: RuntimeError -> params=p0, cov=NaN, success=False
- *   -1     p0 outside bounds or lb>=ub -> reference: ValueError   -> same sentinel
- *   -2     non-finite signal/residual  -> reference: ValueError   -> same sentinel          */
+ *   -1     some lb >= ub               -> reference: ValueError   -> same sentinel
+ *   -2     non-finite signal           -> reference: ValueError (asarray_chkfinite) -> same sentinel
+ *   -3     p0 outside its bounds       -> reference: ValueError   -> same sentinel
+ *   -4     non-finite residual at p0   -> reference: ValueError   -> same sentinel          */
 /* Per-voxel status written by pnx_nnls_batch_f64 (int8):
  *    1 converged; 0 iteration limit (`iteration == max_iter`) -> zeros, ||y||; -2 non-finite input */
 

@@ -695,13 +695,14 @@ static void compute_jac(prob_t *P, int jac_mode, const double *x, const double *
         jac_analytic(P, x, J);
 }
 
-/* status: 1..4 scipy termination (success), 0 = max_nfev reached, -1 bad bounds / p0, -2 non-finite data */
+/* status: 1..4 scipy termination (success), 0 = max_nfev reached, -1 lb>=ub, -2 non-finite signal,
+ * -3 p0 outside bounds, -4 non-finite residual at p0 (same codes as include/pnx.h) */
 static int fit_one(prob_t *P, const double *p0, const double *lb, const double *ub, int max_nfev, double ftol,
                    double xtol, double gtol, int jac_mode, double *xout, double *pcov, int *nfev_out, double *cost_out,
                    int *njev_out)
 {
     const int n = P->n_free, m = P->m;
-    double x[PNXO_MAXN], f[PNXO_MAXM], J[PNXO_MAXM * PNXO_MAXN], g[PNXO_MAXN];
+    double x[PNXO_MAXN], f[PNXO_MAXM], J[PNXO_MAXM * PNXO_MAXN], g[PNXO_MAXN] = {0};
     *nfev_out = 0;
     *njev_out = 0;
     *cost_out = NAN;
@@ -710,11 +711,11 @@ static int fit_one(prob_t *P, const double *p0, const double *lb, const double *
     /* least_squares.py:814-821 */
     for (int i = 0; i < n; ++i)
         if (!(lb[i] < ub[i])) return -1;
-    if (!in_bounds(p0, lb, ub, n)) return -1;
+    if (!in_bounds(p0, lb, ub, n)) return -3;
     memcpy(x, p0, sizeof(double) * n);
     make_strictly_feasible(x, lb, ub, n, 1e-10);
     fun(P, x, f);
-    if (!all_finite(f, m)) return -2;
+    if (!all_finite(f, m)) return -4;
     compute_jac(P, jac_mode, x, f, lb, ub, J);
 
     int nfev = 1, njev = 1;

@@ -45,6 +45,34 @@ class CurvefitOpts(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """Make libpnx_hip.so and PyTorch share ONE HIP runtime.
+
+    PyTorch-ROCm wheels bundle their own `libamdhip64.so` (SONAME libamdhip64.so.7).  If libpnx_hip.so were
+    loaded first it would pull in /opt/rocm's copy, torch would then load its bundled one, and the process would
+    hold two HIP runtimes (streams / device pointers of one are meaningless to the other; the second one does
+    not even see the GPU).  Loading torch's copy first registers the SONAME, so libpnx_hip.so binds to it.
+    Without PyTorch installed the system ROCm runtime is used.
+    """
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libpnx_hip.so (building it is __graft_entry__.build()'s / `python -m pyneapple_amd._build`'s job)."""
     global _lib
@@ -54,6 +82,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first (python -m pyneapple_amd._build). "
             "pyneapple_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, dp, fp = C.c_void_p, C.c_void_p, C.c_void_p
     lib.pnx_version.restype = C.c_int

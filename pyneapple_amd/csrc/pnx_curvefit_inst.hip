@@ -12,8 +12,12 @@ namespace pnx {
 template <int MODEL, int N, bool FD>
 static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stream) {
     auto kern = curvefit_kernel<MODEL, N, FD>;
-    const int block = 256;
-    const size_t shmem = sizeof(double) * (kMaxB + (size_t)(block / kWave) * args.n_b * kWave);
+    // LDS per block: b-value table + one [n_b][64] fp64 signal tile per wave.  Up to 4 waves per block;
+    // fewer when the tiles would not fit 160 KiB (n_b > 79).
+    int waves = 4;
+    while (waves > 1 && sizeof(double) * (kMaxB + (size_t)waves * args.n_b * kWave) > 160 * 1024) waves >>= 1;
+    const int block = waves * kWave;
+    const size_t shmem = sizeof(double) * (kMaxB + (size_t)waves * args.n_b * kWave);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                 finite = finite && isfinite(v);
                 ysh[i * kWave + lane] = v;
             }
-            bool okb = true;
+            bool okb = true, okp = true;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 if (A.per_voxel) {
@@ -575,7 +575,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     lb[k] = A.los[k];
                     ub[k] = A.his[k];
                 }
-                okb = okb && (lb[k] < ub[k]) && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);
+                okb = okb && (lb[k] < ub[k]);                          // least_squares.py:814-816
+                okp = okp && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);  // least_squares.py:818-819
             }
             if (HASFIXED) {
 #pragma unroll
@@ -587,9 +588,9 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                         if (A.fixed_idx[f] == j) pfull[j] = fv;
                 }
             }
-            if (!finite || !okb) {
+            if (!finite || !okb || !okp) {
                 // reference: ValueError inside curve_fit -> params = p0, cov = NaN, success = False
-                const int st = !finite ? -2 : -1;
+                const int st = !finite ? -2 : (!okb ? -1 : -3);
 #pragma unroll
                 for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = p0v[k];
                 if (A.pcov)
@@ -873,7 +874,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         if (state == ST_INIT) {
             if (!finite_f) {
                 // least_squares.py:857-858 "Residuals are not finite in the initial point" -> failure sentinel
-                final_status = -2;
+                final_status = -4;
                 final_cost = NAN;
                 nfev = 0;
                 state = ST_FINAL;

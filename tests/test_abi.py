@@ -1,0 +1,105 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/pnx.h declares;
+host-only entry points are checked for values, GPU entry points for failing loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+from conftest import ROOT, load_golden
+
+from pyneapple_amd import _lib, api
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "pnx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/pnx.h but not exported"
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+
+
+def test_version_and_struct_layout():
+    lib = _lib.load()
+    assert lib.pnx_version() == 1
+    # int32 x4 + 2*int32[8] + int32 x4 + 3 doubles
+    assert C.sizeof(_lib.CurvefitOpts) == 4 * 4 + 2 * 8 * 4 + 4 * 4 + 3 * 8
+    for m, n in enumerate([2, 3, 4, 4, 5, 6, 6]):
+        assert lib.pnx_model_n_params(m) == n
+    assert lib.pnx_model_n_params(99) < 0 and "unknown model" in _lib.last_error()
+
+
+def test_regularization_matrix_entries():
+    # same facts the reference pins in tests/test_solver_nnls.py:251-315
+    n, mu = 7, 0.5
+    assert (api.nnls_regularization_matrix(n, 0, mu) == 0).all()
+    r1 = api.nnls_regularization_matrix(n, 1, mu)
+    np.testing.assert_array_equal(r1, (np.diag(np.full(n, -1.0)) + np.diag(np.ones(n - 1), 1)) * mu)
+    r2 = api.nnls_regularization_matrix(n, 2, mu)
+    np.testing.assert_array_equal(r2, (np.diag(np.ones(n - 1), -1) + np.diag(np.full(n, -2.0))
+                                       + np.diag(np.ones(n - 1), 1)) * mu)
+    r3 = api.nnls_regularization_matrix(n, 3, mu)
+    np.testing.assert_array_equal(r3, (np.diag(np.ones(n - 2), -2) + np.diag(np.full(n - 1, 2.0), -1)
+                                       + np.diag(np.full(n, -6.0)) + np.diag(np.full(n - 1, 2.0), 1)
+                                       + np.diag(np.ones(n - 2), 2)) * mu)
+    with pytest.raises(_lib.PnxError) as e:
+        api.nnls_regularization_matrix(n, 4, mu)
+    assert "not supported" in str(e.value)
+    d = load_golden("g4_nnls_250_r2")
+    np.testing.assert_array_equal(api.nnls_regularization_matrix(250, 2, 0.02), d["reg"])
+
+
+def test_bins_match_reference():
+    d = load_golden("g4_nnls_250_r2")
+    bins = api.nnls_bins(d["d_range"][0], d["d_range"][1], 250)
+    np.testing.assert_allclose(bins, d["bins"], rtol=1e-14)
+    assert bins[0] == pytest.approx(d["d_range"][0]) and bins[-1] == pytest.approx(d["d_range"][1])
+    ratios = bins[1:] / bins[:-1]
+    np.testing.assert_allclose(ratios, ratios[0], rtol=1e-12)  # log spacing (test_solver_nnls.py:155-191)
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    o = api.make_opts("tri_reduced", 32)
+    o.n_free = 3  # inconsistent with the model
+    one = np.zeros(8)
+    rc = lib.pnx_curvefit_batch_f64(C.byref(o), 1, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), _lib.ptr(one),
+                                    _lib.ptr(one), None, _lib.ptr(one), None, None, None, None, 0, 0, None)
+    assert rc == -1 and "n_free" in _lib.last_error()
+    o = api.make_opts("bi_reduced", 24, fixed_idx=[1], jac="fd")
+    rc = lib.pnx_curvefit_batch_f64(C.byref(o), 1, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), _lib.ptr(one),
+                                    _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, None, None, None, 0, 0, None)
+    assert rc == -2 and "analytic" in _lib.last_error()
+
+
+def test_no_cpu_fallback_without_device():
+    """On a GPU-less host the product path must fail loudly, not fall back to a CPU implementation."""
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    from pyneapple_amd import synth
+
+    b, y, _ = synth.make_numpy("mono", 4, 16)
+    _, p0, lo, hi = synth.shared_arrays("mono")
+    with pytest.raises(_lib.PnxError):
+        api.curvefit("mono", b, y, p0, lo, hi)
+    with pytest.raises(_lib.PnxError):
+        api.nnls(np.ones((4, 3)), None, np.ones((2, 4)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pyneapple_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace(
+                    "never route through oracle/", ""), f"{f} references oracle/"
