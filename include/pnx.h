@@ -111,6 +111,7 @@ int pnx_model_n_params(int model);
  *   popt   (n_free, n_vox)            out, host|device  (curvefit.py:235)
  *   pcov   (n_vox, n_free, n_free)    out or NULL       (curvefit.py:236-243; NaN on failure)
  *   status (n_vox) int8, nfev (n_vox) int32, cost (n_vox) = 0.5*sum(res^2): out, each may be NULL
+ *          (PNX_MEM_DEVICE: status and cost are required when pcov is requested)
  */
 int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const double *b, const double *y,
                            const double *p0, const double *lo, const double *hi, const double *fixed,

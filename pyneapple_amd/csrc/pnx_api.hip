@@ -215,6 +215,11 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     if (rc) return rc;
     PNX_HIP(hipSetDevice(device));
     const int n = o->n_free;
+    if (mem == PNX_MEM_DEVICE) {
+        if (pcov && (!status || !cost))
+            return set_error(PNX_ERR_INVALID, "device mode: pcov needs the status and cost outputs too (the covariance "
+                                              "epilogue kernel reads them)");
+    }
     if (mem == PNX_MEM_DEVICE)
         return curvefit_device(o, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, dev, (hipStream_t)stream);
 
@@ -243,12 +248,12 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     }
     if ((rc = dpopt.alloc(nv * n * sizeof(double)))) return rc;
     if (pcov && (rc = dpcov.alloc(nv * n * n * sizeof(double)))) return rc;
-    if (status && (rc = dstat.alloc(nv))) return rc;
+    if ((status || pcov) && (rc = dstat.alloc(nv))) return rc;
     if (nfev && (rc = dnfev.alloc(nv * sizeof(int32_t)))) return rc;
-    if (cost && (rc = dcost.alloc(nv * sizeof(double)))) return rc;
+    if ((cost || pcov) && (rc = dcost.alloc(nv * sizeof(double)))) return rc;
     rc = curvefit_device(o, n_vox, b, (const double *)dy.p, p0_d, lo_d, hi_d, fx_d, (double *)dpopt.p,
-                         pcov ? (double *)dpcov.p : nullptr, status ? (int8_t *)dstat.p : nullptr,
-                         nfev ? (int32_t *)dnfev.p : nullptr, cost ? (double *)dcost.p : nullptr, dev, st);
+                         pcov ? (double *)dpcov.p : nullptr, (status || pcov) ? (int8_t *)dstat.p : nullptr,
+                         nfev ? (int32_t *)dnfev.p : nullptr, (cost || pcov) ? (double *)dcost.p : nullptr, dev, st);
     if (rc) return rc;
     PNX_HIP(hipMemcpyAsync(popt, dpopt.p, nv * n * sizeof(double), hipMemcpyDeviceToHost, st));
     if (pcov) PNX_HIP(hipMemcpyAsync(pcov, dpcov.p, nv * n * n * sizeof(double), hipMemcpyDeviceToHost, st));

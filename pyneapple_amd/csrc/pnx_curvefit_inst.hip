@@ -34,6 +34,13 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, args);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "curvefit launch: %s", hipGetErrorString(e));
+    if (args.pcov) {
+        const int pb = 256;
+        hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
+                           (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b);
+        e = hipGetLastError();
+        if (e != hipSuccess) return set_error(PNX_ERR_HIP, "pcov launch: %s", hipGetErrorString(e));
+    }
     return PNX_OK;
 }
 

@@ -171,6 +171,30 @@ template <int N> __device__ inline double dotn(const double *a, const double *b)
 }
 template <int N> __device__ inline double normn(const double *a) { return sqrt(dotn<N>(a, a)); }
 
+// Reciprocal / reciprocal square root to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64) and two
+// Newton steps: 5-6 VALU ops instead of the 11 (fdiv) / 18 (sqrt) of the IEEE-exact expansions.  Used only
+// inside orthogonal transformations (Householder, Givens/Jacobi), where a last-bit error perturbs
+// orthogonality at the 1e-16 level and nothing else.  Arguments are finite and > 0.
+__device__ inline double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// returns sqrt(x), *rs = 1/sqrt(x)
+__device__ inline double fast_sqrt_rsqrt(double x, double *rs) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    *rs = h + h;
+    return g;
+}
+
 // Merge RB rows (J part in blk[r][0..N), rhs in blk[r][N]) into the upper-triangular factor R | q
 // by Householder reflections acting on [R[k][k]; blk[:,k]].  Afterwards blk is garbage.
 template <int N, int RB> __device__ inline void qr_merge(double (&R)[N][N], double (&q)[N], double (&blk)[RB][N + 1]) {
@@ -181,11 +205,12 @@ template <int N, int RB> __device__ inline void qr_merge(double (&R)[N][N], doub
         for (int r = 0; r < RB; ++r) sig += blk[r][k] * blk[r][k];
         if (sig > 0) {
             const double alpha = R[k][k];
-            const double nrm = sqrt(alpha * alpha + sig);
+            double rs;
+            const double nrm = fast_sqrt_rsqrt(alpha * alpha + sig, &rs);
             const double beta = alpha <= 0 ? nrm : -nrm;
-            const double v0 = alpha - beta;
-            const double inv_v0 = 1.0 / v0;
-            const double tau = -v0 / beta;
+            const double v0 = alpha - beta;            // |v0| >= nrm > 0
+            const double inv_v0 = copysign(fast_rcp(fabs(v0)), v0);
+            const double tau = -v0 * (alpha <= 0 ? rs : -rs);  // -v0 / beta
 #pragma unroll
             for (int r = 0; r < RB; ++r) blk[r][k] *= inv_v0;
             R[k][k] = beta;
@@ -207,15 +232,18 @@ template <int N, int RB> __device__ inline void qr_merge(double (&R)[N][N], doub
 }
 
 // One-sided Jacobi SVD of the N x N matrix W (in place: W <- U*diag(s)), V accumulates the right
-// singular vectors (columns).
+// singular vectors (columns).  Callers pass the TRANSPOSE of a triangular factor (lower triangular W):
+// row-cyclic Jacobi converges in ~1 sweep less on R^T than on R (Drmac-Veselic), see DESIGN.md.
+// A sweep whose largest |cos(angle)| was below 1e-8 is the last one: Jacobi converges quadratically, so the
+// rotations of that sweep already leave the off-diagonal at the 1e-16 level.
 template <int N> __device__ inline void jacobi_svd(double (&W)[N][N], double (&V)[N][N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     if (N == 1) return;
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        bool rotated = false;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double worst = 0;  // max g^2 / (a b) over the pairs of this sweep
 #pragma unroll
         for (int p = 0; p < N - 1; ++p) {
 #pragma unroll
@@ -227,11 +255,18 @@ template <int N> __device__ inline void jacobi_svd(double (&W)[N][N], double (&V
                     b += W[i][q] * W[i][q];
                     g += W[i][p] * W[i][q];
                 }
-                if (fabs(g) > 1.0e-16 * sqrt(a * b)) {
-                    rotated = true;
-                    const double zeta = (b - a) / (2.0 * g);
-                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                const double g2 = g * g, ab = a * b;
+                if (g2 > 1.0e-30 * ab) {  // |cos| > 1e-15
+                    worst = fmax(worst, g2 / ab);
+                    // t = tan(theta) = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  zeta = (b - a) / (2 g)
+                    const double num = b - a, den = 2.0 * g;
+                    double rs;
+                    const double hyp = fast_sqrt_rsqrt(num * num + den * den, &rs);
+                    double t = fabs(den) * fast_rcp(fabs(num) + hyp);
+                    t = ((num < 0) != (den < 0)) ? -t : t;
+                    double c;
+                    (void)fast_sqrt_rsqrt(1.0 + t * t, &c);
+                    const double s = c * t;
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         const double wp = W[i][p], wq = W[i][q];
@@ -244,7 +279,7 @@ template <int N> __device__ inline void jacobi_svd(double (&W)[N][N], double (&V
                 }
             }
         }
-        if (!rotated) break;
+        if (worst < 1.0e-16) break;
     }
 }
 
@@ -659,12 +694,14 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                         blk[i][N] = 0.0;
                     }
                     qr_merge<N, N>(R2, q2, blk);
-                    double W[N][N];
+                    // SVD of R2 through one-sided Jacobi on W = R2^T (lower triangular):  W Vw = Uw S  =>
+                    // R2 = Vw S Uw^T: right singular vectors of J_aug = normalised columns of W, uf = Vw^T q2.
+                    double W[N][N], Vw[N][N];
 #pragma unroll
                     for (int i = 0; i < N; ++i)
 #pragma unroll
-                        for (int j = 0; j < N; ++j) W[i][j] = (j >= i) ? R2[i][j] : 0.0;
-                    jacobi_svd<N>(W, V);
+                        for (int j = 0; j < N; ++j) W[i][j] = (i >= j) ? R2[j][i] : 0.0;
+                    jacobi_svd<N>(W, Vw);
                     smax = 0;
                     smin = INFINITY;
 #pragma unroll
@@ -673,11 +710,14 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #pragma unroll
                         for (int i = 0; i < N; ++i) {
                             nn += W[i][k] * W[i][k];
-                            dq += W[i][k] * q2[i];
+                            dq += Vw[i][k] * q2[i];
                         }
                         nn = sqrt(nn);
+                        const double inv = nn > 0 ? 1.0 / nn : 0.0;
                         s[k] = nn;
-                        uf[k] = nn > 0 ? dq / nn : 0.0;
+                        uf[k] = dq;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) V[i][k] = W[i][k] * inv;
                         smax = fmax(smax, nn);
                         smin = fmin(smin, nn);
                     }
@@ -714,47 +754,15 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             if (A.nfev) A.nfev[vox] = nfev;
             if (A.cost) A.cost[vox] = final_cost;
             if (A.pcov) {
+                // The covariance needs another n x n SVD; doing it here would run it with a handful of lanes
+                // active in (almost) every loop iteration.  The packed R factor of the final Jacobian is parked
+                // in the voxel's pcov slot instead and pcov_kernel turns it into pcov with all lanes busy.
                 double *pc = A.pcov + (size_t)vox * N * N;
-                if (!ok) {
-                    for (int k = 0; k < N * N; ++k) pc[k] = NAN;
-                } else {
-                    // _minpack_py.py:1036-1066: pinv(J^T J) from the SVD of J (= SVD of its R factor), * cost/(m-n)
-                    double W[N][N], Vc[N][N], sv[N];
+                int t = 0;
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
+                for (int i = 0; i < N; ++i)
 #pragma unroll
-                        for (int j = 0; j < N; ++j) W[i][j] = (j >= i) ? R[i][j] : 0.0;
-                    jacobi_svd<N>(W, Vc);
-                    double sm = 0;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        double nn = 0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) nn += W[i][k] * W[i][k];
-                        sv[k] = sqrt(nn);
-                        sm = fmax(sm, sv[k]);
-                    }
-                    const double thr = kEps * (n_b > N ? n_b : N) * sm;
-                    const bool dof = n_b > N;
-                    const double s_sq = dof ? 2.0 * final_cost / (double)(n_b - N) : 0.0;
-                    bool bad = false;
-                    double out[N][N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-#pragma unroll
-                        for (int j = 0; j < N; ++j) {
-                            double a = 0;
-#pragma unroll
-                            for (int k = 0; k < N; ++k)
-                                if (sv[k] > thr) a += Vc[i][k] * Vc[j][k] / (sv[k] * sv[k]);
-                            out[i][j] = a;
-                            bad = bad || isnan(a);
-                        }
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-#pragma unroll
-                        for (int j = 0; j < N; ++j) pc[i * N + j] = (bad || !dof) ? INFINITY : out[i][j] * s_sq;
-                }
+                    for (int j = i; j < N; ++j) pc[t++] = R[i][j];
             }
             state = ST_IDLE;
             continue;
@@ -778,7 +786,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #pragma unroll
                 for (int j = 0; j < NALL; ++j) pe[j] = xn[j];
             }
-            double hpert[N], inv_dx[N];
+            double dxv[N];
             if (FD) {
                 // _numdiff.py:146-163 (_compute_absolute_step) and :13-90 ('1-sided', num_steps = 1)
 #pragma unroll
@@ -791,9 +799,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     const bool fitting = fabs(h) <= fmax(lower_dist, upper_dist);
                     if (violated && fitting) h = -h;
                     if (!fitting) h = (upper_dist >= lower_dist) ? upper_dist : -lower_dist;
-                    const double x1 = xn[k] + h;
-                    hpert[k] = x1;               // perturbed value
-                    inv_dx[k] = 1.0 / (x1 - xn[k]);
+                    dxv[k] = (xn[k] + h) - xn[k];  // _numdiff.py:596 "recompute dx as exactly representable number"
                 }
             }
 #pragma unroll
@@ -818,29 +824,30 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
                     const double r0 = M::signal(pe, E) - yi;
                     double jr[N];
-                    if (FD) {
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const int c = comp_of_param<MODEL>(k);
-                            double rk;
-                            if (c >= 0) {
-                                double E2[NC];
-#pragma unroll
-                                for (int cc = 0; cc < NC; ++cc) E2[cc] = E[cc];
-                                E2[c] = exp(nb * hpert[k]);
-                                rk = M::signal(pe, E2) - yi;
-                            } else {
-                                double p2[NALL];
-#pragma unroll
-                                for (int j = 0; j < NALL; ++j) p2[j] = pe[j];
-                                p2[k] = hpert[k];
-                                rk = M::signal(p2, E) - yi;
-                            }
-                            jr[k] = (rk - r0) * inv_dx[k];
-                        }
-                    } else {
+                    {
                         double ja[NALL];
                         M::jac(pe, E, bb, ja);
+                        if (FD) {
+                            // SciPy's 2-point quotient (f(x + dx e_k) - f(x)) / dx in closed form.  The models are
+                            // linear in every parameter except the D_c, and for a D_c
+                            //   f(D_c + dx) - f(D_c) = w_c exp(-b D_c) (exp(-b dx) - 1),
+                            // so the quotient is the analytic column times g(z) = expm1(z)/z, z = -b dx: no second
+                            // exp per column, no cancellation, and SciPy's deterministic O(dx) bias (up to 1e-5
+                            // relative at b = 1200) -- which is what separates its iterates from an
+                            // analytic-Jacobian run -- is kept exactly.
+#pragma unroll
+                            for (int k = 0; k < N; ++k) {
+                                if (comp_of_param<MODEL>(k) >= 0) {
+                                    const double z = nb * dxv[k];
+                                    double gz;
+                                    if (fabs(z) < 1e-3)
+                                        gz = 1.0 + z * (0.5 + z * (1.0 / 6 + z * (1.0 / 24 + z * (1.0 / 120 + z * (1.0 / 720)))));
+                                    else
+                                        gz = expm1(z) / z;
+                                    ja[k] *= gz;
+                                }
+                            }
+                        }
                         if (HASFIXED) {
 #pragma unroll
                             for (int k = 0; k < N; ++k) {
@@ -943,6 +950,70 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Covariance epilogue (one lane per voxel, fully convergent): turns the packed R factor of the final
+// Jacobian that curvefit_kernel parked in pcov[vox] into SciPy's pcov
+//   pinv(J^T J) * 2 cost / (m - n)   with singular values <= eps * max(m, n) * s_max dropped
+// (scipy/optimize/_minpack_py.py:1036-1066), NaN for failed voxels (curvefit.py:236-243, 312-317).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(256) pcov_kernel(double *pcov, const int8_t *status, const double *cost,
+                                                   long long n_vox, int n_b) {
+    const long long vox = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= n_vox) return;
+    double *pc = pcov + (size_t)vox * N * N;
+    if (status[vox] <= 0) {
+#pragma unroll
+        for (int k = 0; k < N * N; ++k) pc[k] = NAN;
+        return;
+    }
+    double W[N][N], Vw[N][N];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) W[i][j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) W[j][i] = pc[t++];  // W = R^T
+    }
+    jacobi_svd<N>(W, Vw);
+    double s2[N], sm = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) nn += W[i][k] * W[i][k];
+        s2[k] = nn;
+        sm = fmax(sm, nn);
+    }
+    const double thr = kEps * (n_b > N ? n_b : N) * sqrt(sm);
+    const bool dof = n_b > N;
+    const double s_sq = dof ? 2.0 * cost[vox] / (double)(n_b - N) : 0.0;
+    double wgt[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) wgt[k] = (sqrt(s2[k]) > thr) ? 1.0 / (s2[k] * s2[k]) : 0.0;  // V_k V_k^T / s_k^2 = w_k w_k^T / s_k^4
+    bool bad = false;
+    double out[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double a = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) a += W[i][k] * W[j][k] * wgt[k];
+            out[i][j] = a;
+            bad = bad || isnan(a);
+        }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) pc[i * N + j] = (bad || !dof) ? INFINITY : out[i][j] * s_sq;
 }
 
 }  // namespace pnx
