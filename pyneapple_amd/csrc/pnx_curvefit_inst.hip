@@ -9,15 +9,17 @@
 
 namespace pnx {
 
-template <int MODEL, int N, bool FD>
+template <int MODEL, int N, bool FD, bool PV>
 static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stream) {
-    auto kern = curvefit_kernel<MODEL, N, FD>;
-    // LDS per block: b-value table + one [n_b][64] fp64 signal tile per wave.  Up to 4 waves per block;
-    // fewer when the tiles would not fit 160 KiB (n_b > 79).
+    auto kern = curvefit_kernel<MODEL, N, FD, PV>;
+    // LDS per block: b-value table + per wave: [n_b][64] signal tile, parked R factor and singular vectors.
+    // Up to 4 waves per block; fewer when that would not fit 160 KiB.
     int waves = 4;
-    while (waves > 1 && sizeof(double) * (kMaxB + (size_t)waves * args.n_b * kWave) > 160 * 1024) waves >>= 1;
+    auto bytes = [&](int w) { return sizeof(double) * (kMaxB + (size_t)w * Park<N>::per_wave(args.n_b)); };
+    while (waves > 1 && bytes(waves) > 160 * 1024) --waves;
+    if (bytes(waves) > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", args.n_b);
     const int block = waves * kWave;
-    const size_t shmem = sizeof(double) * (kMaxB + (size_t)waves * args.n_b * kWave);
+    const size_t shmem = bytes(waves);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -44,16 +46,20 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     return PNX_OK;
 }
 
+template <int MODEL, int N, bool FD> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
+    return args.per_voxel ? launch_one<MODEL, N, FD, true>(args, cus, st) : launch_one<MODEL, N, FD, false>(args, cus, st);
+}
+
 template <int MODEL> static int launch_model(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
     constexpr int NALL = Model<MODEL>::NALL;
     if (n_free == NALL) {
-        if (jac_mode == PNX_JAC_FD) return launch_one<MODEL, NALL, true>(args, cus, st);
-        return launch_one<MODEL, NALL, false>(args, cus, st);
+        if (jac_mode == PNX_JAC_FD) return launch_pv<MODEL, NALL, true>(args, cus, st);
+        return launch_pv<MODEL, NALL, false>(args, cus, st);
     }
     if constexpr (NALL >= 2) {
         if (n_free == NALL - 1) {
             // with fixed parameters the reference always passes the analytic Jacobian (curvefit.py:274-288)
-            return launch_one<MODEL, NALL - 1, false>(args, cus, st);
+            return launch_pv<MODEL, NALL - 1, false>(args, cus, st);
         }
     }
     return set_error(PNX_ERR_UNSUPPORTED, "model %d with %d free parameters is not built (built: %d and %d)", MODEL,

@@ -551,9 +551,29 @@ __device__ inline double select_step(const double *x, const double (&R2)[N][N], 
 // ---------------------------------------------------------------------------------------------
 enum LaneState : int { ST_IDLE = 0, ST_INIT = 1, ST_RUN = 2, ST_FINAL = 3 };
 
-template <int MODEL, int N, bool FD>
+template <int N> struct Park {
+    static constexpr int NR = N * (N + 1) / 2;          // packed R factor of J at the current iterate (for pcov)
+    static constexpr bool kParkV = (N <= 5);            // right singular vectors live in LDS between B and C
+    static constexpr int NV = kParkV ? N * N : 0;
+    // doubles of LDS per wave besides the b-value table
+    __host__ __device__ static constexpr int per_wave(int n_b) { return kWave * (n_b + NR + NV); }
+};
+
+// Loop order -- one iteration = one row pass per lane:
+//   refill   idle lanes pull the next voxel (x_new = strictly feasible p0) or leave for good;
+//   pass     residual / cost / Jacobian / J^T f / QR(J) at x_new  (every lane);
+//   D        accept or reject, trust radius, ftol / xtol tests;
+//   B-light  Coleman-Li scaling + gtol test for lanes whose iterate changed or that are about to stop;
+//   final    lanes that stop write their outputs and become idle (refilled at the top of the next iteration,
+//            so a finished voxel never costs a wasted pass);
+//   B-heavy  lanes that accepted: QR of the augmented factor + Jacobi SVD (consumes the pass's R directly);
+//   C        trust-region step -> next x_new.
+// Register diet: bounds stay in SGPRs unless they are per voxel (PV); R (for the covariance) and the
+// singular vectors V are parked in LDS; nothing produced by the pass stays live across the next pass.
+template <int MODEL, int N, bool FD, bool PV>
 __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     using M = Model<MODEL>;
+    using PK = Park<N>;
     constexpr int NALL = M::NALL;
     constexpr int NC = M::NC;
     constexpr bool HASFIXED = (N != NALL);
@@ -564,52 +584,56 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     double *bsh = smem;                                   // [kMaxB]
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    double *ysh = smem + kMaxB + (size_t)wave * n_b * kWave;  // [n_b][64]
+    double *ysh = smem + kMaxB + (size_t)wave * PK::per_wave(n_b) + lane;  // [n_b][64]
+    double *rpark = ysh + (size_t)n_b * kWave;                                // [NR][64]
+    double *vpark = rpark + (size_t)PK::NR * kWave;                           // [NV][64]
     for (int i = threadIdx.x; i < n_b; i += blockDim.x) bsh[i] = A.b[i];
     __syncthreads();
 
     // ---- per-lane persistent state
     int state = ST_IDLE;
     long long vox = -1;
-    double x[N], lb[N], ub[N], p0v[N];
+    double x[N], lb[N], ub[N];
     double pfull[NALL];
-    double g[N], R[N][N], qtf[N];          // at the current iterate x
-    double s[N], uf[N], V[N][N], R2[N][N]; // SVD data of the augmented hat-space Jacobian at x
-    double d[N], g_h[N];
+    double g[N];
+    double s[N], uf[N], R2[N][N], d[N], g_h[N];
+    double Vreg[PK::kParkV ? 1 : N][PK::kParkV ? 1 : N];
     double smax = 0, smin = 0, theta = 0;
     double cost = 0, Delta = 0, alpha = 0;
     int nfev = 0, term = -99;
-    bool needB = false, first = false;
-    // trial point
+    bool first = false;
     double xn[N], step_h_norm = 0, step_norm = 0, predicted = 0;
-    int final_status = 0;
-    double final_cost = 0;
+    if (!PV) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {  // wave-uniform, never written again: stays in SGPRs
+            lb[k] = A.los[k];
+            ub[k] = A.his[k];
+        }
+    }
 
     for (;;) {
         // ------------------------------------------------------------------ refill
-        if (state == ST_IDLE) {
+        while (state == ST_IDLE) {
             const unsigned long long idx = atomicAdd(A.queue, 1ULL);
             if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
             vox = (long long)idx;
             bool finite = true;
             const double *yv = A.y + (size_t)vox * n_b;
             for (int i = 0; i < n_b; ++i) {
-                const double v = yv[i];
-                finite = finite && isfinite(v);
-                ysh[i * kWave + lane] = v;
+                const double yy = yv[i];
+                finite = finite && isfinite(yy);
+                ysh[i * kWave] = yy;
             }
             bool okb = true, okp = true;
+            double p0v[N];
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                if (A.per_voxel) {
+                if (PV) {
                     p0v[k] = A.p0[(size_t)k * A.n_vox + vox];
                     lb[k] = A.lo[(size_t)k * A.n_vox + vox];
                     ub[k] = A.hi[(size_t)k * A.n_vox + vox];
-                } else {
+                } else
                     p0v[k] = A.p0s[k];
-                    lb[k] = A.los[k];
-                    ub[k] = A.his[k];
-                }
                 okb = okb && (lb[k] < ub[k]);                          // least_squares.py:814-816
                 okp = okp && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);  // least_squares.py:818-819
             }
@@ -628,9 +652,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                 const int st = !finite ? -2 : (!okb ? -1 : -3);
 #pragma unroll
                 for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = p0v[k];
-                if (A.pcov)
-                    for (int k = 0; k < N * N; ++k) A.pcov[(size_t)vox * N * N + k] = NAN;
-                if (A.status) A.status[vox] = (int8_t)st;
+                if (A.status) A.status[vox] = (int8_t)st;  // pcov_kernel writes the NaN covariance
                 if (A.nfev) A.nfev[vox] = 0;
                 if (A.cost) A.cost[vox] = NAN;
                 continue;  // stays IDLE -> next voxel
@@ -641,135 +663,11 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             nfev = 0;
             term = -99;
             alpha = 0.0;
-            needB = false;
-        } else if (state == ST_RUN) {
-            // -------------------------------------------------------------- phase B: SVD at the current x
-            if (needB) {
-                double v[N], dv[N], diag_h[N];
-                double g_norm = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {  // CL_scaling_vector (common.py:467-508)
-                    v[i] = 1.0;
-                    dv[i] = 0.0;
-                    if (g[i] < 0 && isfinite(ub[i])) {
-                        v[i] = ub[i] - x[i];
-                        dv[i] = -1;
-                    }
-                    if (g[i] > 0 && isfinite(lb[i])) {
-                        v[i] = x[i] - lb[i];
-                        dv[i] = 1;
-                    }
-                    g_norm = fmax(g_norm, fabs(g[i] * v[i]));
-                }
-                if (first) {  // trf.py:232-236
-                    double t = 0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const double q = x[i] / sqrt(v[i]);
-                        t += q * q;
-                    }
-                    Delta = sqrt(t);
-                    if (Delta == 0) Delta = 1.0;
-                    first = false;
-                }
-                if (g_norm < A.gtol) term = 1;
-                if (term == -99 && nfev != A.max_nfev) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        d[i] = sqrt(v[i]);
-                        diag_h[i] = g[i] * dv[i];
-                        g_h[i] = d[i] * g[i];
-                    }
-                    // QR of [R*D; diag(sqrt(diag_h))] -> R2, q2 ;  J_aug = Q R2 (trf.py:300-306)
-                    double q2[N];
-                    double blk[N][N + 1];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        q2[i] = qtf[i];
-#pragma unroll
-                        for (int j = 0; j < N; ++j) {
-                            R2[i][j] = (j >= i) ? R[i][j] * d[j] : 0.0;
-                            blk[i][j] = (i == j) ? sqrt(diag_h[i]) : 0.0;
-                        }
-                        blk[i][N] = 0.0;
-                    }
-                    qr_merge<N, N>(R2, q2, blk);
-                    // SVD of R2 through one-sided Jacobi on W = R2^T (lower triangular):  W Vw = Uw S  =>
-                    // R2 = Vw S Uw^T: right singular vectors of J_aug = normalised columns of W, uf = Vw^T q2.
-                    double W[N][N], Vw[N][N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-#pragma unroll
-                        for (int j = 0; j < N; ++j) W[i][j] = (i >= j) ? R2[j][i] : 0.0;
-                    jacobi_svd<N>(W, Vw);
-                    smax = 0;
-                    smin = INFINITY;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        double nn = 0, dq = 0;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) {
-                            nn += W[i][k] * W[i][k];
-                            dq += Vw[i][k] * q2[i];
-                        }
-                        nn = sqrt(nn);
-                        const double inv = nn > 0 ? 1.0 / nn : 0.0;
-                        s[k] = nn;
-                        uf[k] = dq;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) V[i][k] = W[i][k] * inv;
-                        smax = fmax(smax, nn);
-                        smin = fmin(smin, nn);
-                    }
-                    theta = fmax(0.995, 1 - g_norm);
-                }
-                needB = false;
-            }
-            if (term != -99 || nfev >= A.max_nfev) {
-                // trf.py:263-272: leave the outer loop
-                final_status = (term == -99) ? 0 : term;
-                final_cost = cost;
-                // the QR factor of J at the final x is in R (x was either never moved or R was swapped in)
-                state = ST_FINAL;
-            } else {
-                // ---------------------------------------------------------- phase C: trial step
-                double p_h[N], p[N], step[N], step_h[N];
-                alpha = solve_lsq_trust_region<N>(n_b, uf, s, V, smax, smin, Delta, alpha, p_h);
-#pragma unroll
-                for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
-                predicted = select_step<N>(x, R2, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
-#pragma unroll
-                for (int i = 0; i < N; ++i) xn[i] = strictly_feasible0(x[i] + step[i], lb[i], ub[i]);
-                step_h_norm = normn<N>(step_h);
-                step_norm = normn<N>(step);
-            }
         }
-
-        if (state == ST_FINAL) {
-            // ---------------------------------------------------------------- outputs
-            const bool ok = final_status > 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = ok ? x[k] : p0v[k];
-            if (A.status) A.status[vox] = (int8_t)final_status;
-            if (A.nfev) A.nfev[vox] = nfev;
-            if (A.cost) A.cost[vox] = final_cost;
-            if (A.pcov) {
-                // The covariance needs another n x n SVD; doing it here would run it with a handful of lanes
-                // active in (almost) every loop iteration.  The packed R factor of the final Jacobian is parked
-                // in the voxel's pcov slot instead and pcov_kernel turns it into pcov with all lanes busy.
-                double *pc = A.pcov + (size_t)vox * N * N;
-                int t = 0;
-#pragma unroll
-                for (int i = 0; i < N; ++i)
-#pragma unroll
-                    for (int j = i; j < N; ++j) pc[t++] = R[i][j];
-            }
-            state = ST_IDLE;
-            continue;
-        }
+        if (state == ST_IDLE) break;
 
         // ------------------------------------------------------------------ row pass at xn
-        // residual f = model(xn) - y, cost, speculative Jacobian (FD or analytic), g = J^T f, QR of J
+        // residual f = model(xn) - y, cost, Jacobian (closed-form 2-point FD or analytic), g = J^T f, QR of J
         double Rn[N][N], qn[N], gn[N], cost_new = 0;
         bool finite_f = true;
         {
@@ -818,7 +716,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     const int ii = live ? i : 0;
                     const double bb = bsh[ii];
                     const double nb = -bb;
-                    const double yi = ysh[ii * kWave + lane];
+                    const double yi = ysh[ii * kWave];
                     double E[NC];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
@@ -878,31 +776,23 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         }
 
         // ------------------------------------------------------------------ phase D: accept / reject
+        bool accepted = false;
+        int final_status = 0;
         if (state == ST_INIT) {
             if (!finite_f) {
                 // least_squares.py:857-858 "Residuals are not finite in the initial point" -> failure sentinel
                 final_status = -4;
-                final_cost = NAN;
+                cost = NAN;
                 nfev = 0;
                 state = ST_FINAL;
             } else {
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    x[i] = xn[i];
-                    g[i] = gn[i];
-                    qtf[i] = qn[i];
-#pragma unroll
-                    for (int j = 0; j < N; ++j) R[i][j] = Rn[i][j];
-                }
-                cost = cost_new;
+                accepted = true;
                 nfev = 1;
-                needB = true;
                 first = true;
                 state = ST_RUN;
             }
         } else {  // ST_RUN
             nfev += 1;
-            bool accept = false;
             if (!finite_f) {
                 Delta = 0.25 * step_h_norm;  // trf.py:337-339
             } else {
@@ -932,26 +822,159 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     alpha *= Delta / Delta_new;
                     Delta = Delta_new;
                 }
-                accept = actual > 0;
+                accepted = actual > 0;
             }
-            if (accept) {
+        }
+        if (accepted) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x[i] = xn[i];
+                g[i] = gn[i];
+            }
+            cost = cost_new;
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = i; j < N; ++j) rpark[(t++) * kWave] = Rn[i][j];
+        }
+
+        // ------------------------------------------------------------------ light head of phase B
+        // (trf.py:260-272: scaling vector, first trust radius, gtol test, leave when done or out of evaluations)
+        double v[N], dv[N], g_norm = 0;
+        if (state == ST_RUN && (accepted || term != -99 || nfev >= A.max_nfev)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {  // CL_scaling_vector (common.py:467-508)
+                v[i] = 1.0;
+                dv[i] = 0.0;
+                if (g[i] < 0 && isfinite(ub[i])) {
+                    v[i] = ub[i] - x[i];
+                    dv[i] = -1;
+                }
+                if (g[i] > 0 && isfinite(lb[i])) {
+                    v[i] = x[i] - lb[i];
+                    dv[i] = 1;
+                }
+                g_norm = fmax(g_norm, fabs(g[i] * v[i]));
+            }
+            if (first) {  // trf.py:232-236
+                double t = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    x[i] = xn[i];
-                    g[i] = gn[i];
-                    qtf[i] = qn[i];
-#pragma unroll
-                    for (int j = 0; j < N; ++j) R[i][j] = Rn[i][j];
+                    const double q = x[i] / sqrt(v[i]);
+                    t += q * q;
                 }
-                cost = cost_new;
-                needB = true;  // also evaluates the gtol test at the new x (trf.py:263-266)
-            } else if (term != -99 || nfev >= A.max_nfev) {
-                needB = true;  // scipy re-evaluates g_norm < gtol at the (unchanged) x before leaving (trf.py:263-272)
+                Delta = sqrt(t);
+                if (Delta == 0) Delta = 1.0;
+                first = false;
             }
+            if (g_norm < A.gtol) term = 1;
+            if (term != -99 || nfev >= A.max_nfev) {
+                final_status = (term == -99) ? 0 : term;
+                state = ST_FINAL;
+            }
+        }
+
+        // ------------------------------------------------------------------ outputs of finished voxels
+        if (state == ST_FINAL) {
+            const bool ok = final_status > 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                // failure: the reference returns the p0 it was given (curvefit.py:308-317)
+                const double pk = ok ? x[k] : (PV ? A.p0[(size_t)k * A.n_vox + vox] : A.p0s[k]);
+                A.popt[(size_t)k * A.n_vox + vox] = pk;
+            }
+            if (A.status) A.status[vox] = (int8_t)final_status;
+            if (A.nfev) A.nfev[vox] = nfev;
+            if (A.cost) A.cost[vox] = cost;
+            if (A.pcov && ok) {
+                // The covariance needs another n x n SVD; done here it would run with a handful of lanes active
+                // in (almost) every loop iteration.  The packed R factor of the final Jacobian goes to the voxel's
+                // pcov slot instead and pcov_kernel turns it into pcov with all lanes busy.
+                double *pc = A.pcov + (size_t)vox * N * N;
+#pragma unroll
+                for (int t = 0; t < PK::NR; ++t) pc[t] = rpark[t * kWave];
+            }
+            state = ST_IDLE;
+        }
+
+        if (state == ST_RUN) {
+            // -------------------------------------------------------------- heavy phase B (iterate changed)
+            if (accepted) {
+                double diag_h[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    d[i] = sqrt(v[i]);
+                    diag_h[i] = g[i] * dv[i];
+                    g_h[i] = d[i] * g[i];
+                }
+                // QR of [R*D; diag(sqrt(diag_h))] -> R2, q2 ;  J_aug = Q R2 (trf.py:300-306)
+                double q2[N];
+                double blk[N][N + 1];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    q2[i] = qn[i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        R2[i][j] = (j >= i) ? Rn[i][j] * d[j] : 0.0;
+                        blk[i][j] = (i == j) ? sqrt(diag_h[i]) : 0.0;
+                    }
+                    blk[i][N] = 0.0;
+                }
+                qr_merge<N, N>(R2, q2, blk);
+                // SVD of R2 through one-sided Jacobi on W = R2^T (lower triangular):  W Vw = Uw S  =>
+                // R2 = Vw S Uw^T: right singular vectors of J_aug = normalised columns of W, uf = Vw^T q2.
+                double W[N][N], Vw[N][N];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) W[i][j] = (i >= j) ? R2[j][i] : 0.0;
+                jacobi_svd<N>(W, Vw);
+                smax = 0;
+                smin = INFINITY;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    double nn = 0, dq = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        nn += W[i][k] * W[i][k];
+                        dq += Vw[i][k] * q2[i];
+                    }
+                    nn = sqrt(nn);
+                    const double inv = nn > 0 ? 1.0 / nn : 0.0;
+                    s[k] = nn;
+                    uf[k] = dq;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        if (PK::kParkV)
+                            vpark[(i * N + k) * kWave] = W[i][k] * inv;
+                        else
+                            Vreg[PK::kParkV ? 0 : i][PK::kParkV ? 0 : k] = W[i][k] * inv;
+                    }
+                    smax = fmax(smax, nn);
+                    smin = fmin(smin, nn);
+                }
+                theta = fmax(0.995, 1 - g_norm);
+            }
+            // -------------------------------------------------------------- phase C: trial step
+            double V[N][N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    V[i][k] = PK::kParkV ? vpark[(i * N + k) * kWave] : Vreg[PK::kParkV ? 0 : i][PK::kParkV ? 0 : k];
+            double p_h[N], p[N], step[N], step_h[N];
+            alpha = solve_lsq_trust_region<N>(n_b, uf, s, V, smax, smin, Delta, alpha, p_h);
+#pragma unroll
+            for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
+            predicted = select_step<N>(x, R2, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xn[i] = strictly_feasible0(x[i] + step[i], lb[i], ub[i]);
+            step_h_norm = normn<N>(step_h);
+            step_norm = normn<N>(step);
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Covariance epilogue (one lane per voxel, fully convergent): turns the packed R factor of the final
