@@ -52,27 +52,60 @@ struct NnlsArgs {
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane reductions on the DPP data path (row_shr 1/2/4/8, row_bcast 15/31): a handful of VALU ops with
+// register-file latency instead of 12 ds_bpermute round trips through the LDS crossbar per fp64 reduction.
+template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ inline double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = ZERO_FILL ? 0 : lo, ohi = ZERO_FILL ? 0 : hi;
+    const int rlo = __builtin_amdgcn_update_dpp(olo, lo, CTRL, ROW_MASK, 0xf, ZERO_FILL);
+    const int rhi = __builtin_amdgcn_update_dpp(ohi, hi, CTRL, ROW_MASK, 0xf, ZERO_FILL);
+    return __hiloint2double(rhi, rlo);
+}
+template <int CTRL, int ROW_MASK> __device__ inline int dpp_mov_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118, kBc15 = 0x142, kBc31 = 0x143;
+
+// inclusive prefix sum over the 64 lanes (lane 63 holds the total)
+__device__ inline double wave_incl_scan(double v, int) {
+    v += dpp_mov<kShr1, 0xf, true>(v);
+    v += dpp_mov<kShr2, 0xf, true>(v);
+    v += dpp_mov<kShr4, 0xf, true>(v);
+    v += dpp_mov<kShr8, 0xf, true>(v);
+    v += dpp_mov<kBc15, 0xa, true>(v);
+    v += dpp_mov<kBc31, 0xc, true>(v);
     return v;
 }
+__device__ inline double bcast_lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum(double v) { return bcast_lane63(wave_incl_scan(v, 0)); }
+__device__ inline double wave_max(double v) {
+    v = fmax(v, dpp_mov<kShr1, 0xf, false>(v));
+    v = fmax(v, dpp_mov<kShr2, 0xf, false>(v));
+    v = fmax(v, dpp_mov<kShr4, 0xf, false>(v));
+    v = fmax(v, dpp_mov<kShr8, 0xf, false>(v));
+    v = fmax(v, dpp_mov<kBc15, 0xa, false>(v));
+    v = fmax(v, dpp_mov<kBc31, 0xc, false>(v));
+    return bcast_lane63(v);
+}
+__device__ inline double wave_min(double v) { return -wave_max(-v); }
 __device__ inline int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const int t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
+    int t;
+    t = dpp_mov_i<kShr1, 0xf>(v); v = t < v ? t : v;
+    t = dpp_mov_i<kShr2, 0xf>(v); v = t < v ? t : v;
+    t = dpp_mov_i<kShr4, 0xf>(v); v = t < v ? t : v;
+    t = dpp_mov_i<kShr8, 0xf>(v); v = t < v ? t : v;
+    t = dpp_mov_i<kBc15, 0xa>(v); v = t < v ? t : v;
+    t = dpp_mov_i<kBc31, 0xc>(v); v = t < v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ inline double wave_incl_scan(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < kW; o <<= 1) {
-        const double t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
+
+// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1} so that one row of G (leading dimension 256,
+// zero padded) is fetched with two 16-byte loads per lane.
+__device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
 
 // Column pass over the packed lower-triangular M: out[s] (k = lane + 64 s) = sum_{i >= k} v[i] * M[i][k].
 // v is an LDS vector (broadcast reads).  Two vectors at once (va, vb) so one sweep of M serves both.
@@ -126,7 +159,8 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
     for (;;) {
         unsigned long long vq = 0;
         if (lane == 0) vq = atomicAdd(A.queue, 1ULL);
-        vq = __shfl(vq, 0);
+        vq = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vq >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
         if (vq >= (unsigned long long)A.n_vox) break;
         const long long vox = (long long)vq;
         const double *yv = A.y + (size_t)vox * nm;
@@ -148,7 +182,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
         bool inP[kSlots];
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
-            const int j = lane + kW * s;
+            const int j = binof(lane, s);
             double acc = 0;
             if (j < n && finite)
                 for (int k = 0; k < nm; ++k) acc += A.B[(size_t)k * n + j] * t1[k];
@@ -162,19 +196,30 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
             // ---- dual w = A^T y - G[:,P] x_P on the zero set
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
-            for (int pos = 0; pos < p; ++pos) {
-                const int col = pidx[pos];
-                const double xp = xv[pos];
-                const double *gc = A.G + (size_t)col * n;
+            // p rows of G (L2 resident), 8 in flight: the rows are independent, only the four accumulators chain
+            for (int pos0 = 0; pos0 < p; pos0 += 8) {
+                double2 ga[8], gb[8];
+                double xs[8];
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    const int j = lane + kW * s;
-                    if (j < n) w[s] -= gc[j] * xp;
+                for (int u = 0; u < 8; ++u) {
+                    const int pos = pos0 + u < p ? pos0 + u : p - 1;
+                    const int col = __builtin_amdgcn_readfirstlane((int)pidx[pos]);
+                    xs[u] = pos0 + u < p ? xv[pos] : 0.0;
+                    const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
+                    ga[u] = *reinterpret_cast<const double2 *>(gc);
+                    gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    w[0] -= ga[u].x * xs[u];
+                    w[1] -= ga[u].y * xs[u];
+                    w[2] -= gb[u].x * xs[u];
+                    w[3] -= gb[u].y * xs[u];
                 }
             }
 #pragma unroll
             for (int s = 0; s < kSlots; ++s)
-                if (inP[s] || lane + kW * s >= n) w[s] = -INFINITY;
+                if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
 
             bool accepted = false;
             int jmax = 0;
@@ -183,33 +228,28 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
                 double best = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) best = fmax(best, w[s]);
+                best = wave_max(best);
                 int bj = kNone;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
-                    if (w[s] > best) {
-                        best = w[s];
-                        bj = lane + kW * s;
-                    }
-#pragma unroll
-                for (int o = 32; o; o >>= 1) {
-                    const double ob = __shfl_xor(best, o);
-                    const int oj = __shfl_xor(bj, o);
-                    if (ob > best || (ob == best && oj < bj)) {
-                        best = ob;
-                        bj = oj;
-                    }
-                }
+                for (int s = kSlots - 1; s >= 0; --s)
+                    if (w[s] == best) bj = binof(lane, s);
+                bj = wave_min_i(bj);  // ties: lowest bin
                 if (!(best > 0)) break;  // KKT satisfied
                 jmax = bj;
                 // ---- g = G[P, jmax] -> t1 ; l = M g
                 __syncthreads();
-                for (int pos = lane; pos < p; pos += kW) t1[pos] = A.G[(size_t)jmax * n + pidx[pos]];
+                for (int pos = lane; pos < p; pos += kW) t1[pos] = A.G[(size_t)jmax * kNnlsMaxBins + pidx[pos]];
                 __syncthreads();
-                const double Gjj = A.G[(size_t)jmax * n + jmax];
-                const double atyj = __shfl(aty[0], jmax & 63) * (double)((jmax >> 6) == 0) +
-                                    __shfl(aty[1], jmax & 63) * (double)((jmax >> 6) == 1) +
-                                    __shfl(aty[2], jmax & 63) * (double)((jmax >> 6) == 2) +
-                                    __shfl(aty[3], jmax & 63) * (double)((jmax >> 6) == 3);
+                const double Gjj = A.G[(size_t)jmax * kNnlsMaxBins + jmax];
+                double atyj;
+                {
+                    const int ol = (jmax & 127) >> 1, os = ((jmax >> 7) << 1) | (jmax & 1);  // owner lane / slot
+                    const double av = os == 0 ? aty[0] : (os == 1 ? aty[1] : (os == 2 ? aty[2] : aty[3]));
+                    atyj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(av), ol),
+                                            __builtin_amdgcn_readlane(__double2loint(av), ol));
+                }
                 double ll = 0, lq = 0;
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
@@ -217,9 +257,14 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                     const int i = lane + kW * s;
                     if (kW * s < p) {
                         if (i < p) {
-                            const double *row = (s == 0) ? (Mlds + tri(i)) : (Mg + (tri(i) - kLdsTri));
                             double acc = 0;
-                            for (int k = 0; k <= i; ++k) acc += row[k] * t1[k];
+                            if (s == 0) {
+                                const double *row = Mlds + tri(i);
+                                for (int k = 0; k <= i; ++k) acc += row[k] * t1[k];
+                            } else {
+                                const double *row = Mg + (tri(i) - kLdsTri);
+                                for (int k = 0; k <= i; ++k) acc += row[k] * t1[k];
+                            }
                             l[s] = acc;
                             ll += acc * acc;
                             lq += acc * qv[i];
@@ -246,7 +291,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s)
-                    if (lane + kW * s == jmax) w[s] = 0.0;
+                    if (binof(lane, s) == jmax) w[s] = 0.0;
             }
             if (!accepted) break;
 #ifdef PNX_NNLS_TRACE
@@ -277,7 +322,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                         rowp[k] = inv;
                         z[s] = qn * inv;
                     }
-                    if (k == jmax) inP[s] = true;
+                    if (binof(lane, s) == jmax) inP[s] = true;
                 }
                 if (lane == 0) {
                     qv[p] = qn;
@@ -309,14 +354,11 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o; o >>= 1) {
-                    const double oT = __shfl_xor(bestT, o);
-                    const int op = __shfl_xor(bpos, o);
-                    if (oT < bestT || (oT == bestT && op < bpos)) {
-                        bestT = oT;
-                        bpos = op;
-                    }
+                {
+                    const double gmin = wave_min(bestT);
+                    bpos = (bestT == gmin && bpos != kNone) ? bpos : kNone;
+                    bpos = wave_min_i(bpos);  // ties: first position (Lawson-Hanson keeps the first minimum)
+                    bestT = gmin;
                 }
                 __syncthreads();
                 if (bpos == kNone) {
@@ -352,12 +394,11 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                         mv[s] = 0;
                         if (kW * s < p) {
                             if (i >= jj && i < p) {
-                                const double *row = (s == 0) ? (Mlds + tri(i)) : (Mg + (tri(i) - kLdsTri));
-                                mv[s] = row[jj];
+                                mv[s] = (s == 0) ? Mlds[tri(i) + jj] : Mg[tri(i) - kLdsTri + jj];
                             }
                             const double sc = wave_incl_scan(mv[s] * mv[s], lane);
                             pre[s] = sc + carry;
-                            carry += __shfl(sc, 63);
+                            carry += bcast_lane63(sc);
                             if (i < p) {
                                 t1[i] = pre[s];
                                 t2[i] = mv[s];
@@ -452,7 +493,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                             xv[i] = xs[s];
                             pidx[i] = ps[s];
                         }
-                        if (lane + kW * s == bin_out) inP[s] = false;
+                        if (binof(lane, s) == bin_out) inP[s] = false;
                     }
                     p -= 1;
                     __syncthreads();
@@ -523,7 +564,7 @@ __global__ void gram_kernel(const double *B, const double *RT, int nm, int n, in
     double acc = 0;
     for (int k = 0; k < nm; ++k) acc += B[(size_t)k * n + i] * B[(size_t)k * n + j];
     for (int r = 0; r < nreg; ++r) acc += RT[(size_t)i * nreg + r] * RT[(size_t)j * nreg + r];
-    G[(size_t)i * n + j] = acc;
+    G[(size_t)i * kNnlsMaxBins + j] = acc;
 }
 
 __global__ void basis_kernel(const double *b, const double *bins, int nm, int n, double *out) {
@@ -548,12 +589,13 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     P->n_meas = n_meas;
     P->n_bins = n_bins;
     P->n_reg = n_reg;
-    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)n_bins * n_bins;
+    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)n_bins * kNnlsMaxBins;
     for (size_t i = 0; i < nb; ++i)
         if (!std::isfinite(basis[i])) return set_error(PNX_ERR_INVALID, "basis contains non-finite values");
     PNX_HIPN(hipMalloc(&P->B, nb * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->RT, (nr ? nr : 1) * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->G, ng * sizeof(double)));
+    PNX_HIPN(hipMemset(P->G, 0, ng * sizeof(double)));  // rows padded to 256 columns
     PNX_HIPN(hipMalloc(&P->queue, sizeof(unsigned long long)));
     PNX_HIPN(hipMemcpy(P->B, basis, nb * sizeof(double), hipMemcpyHostToDevice));
     if (nr) {
