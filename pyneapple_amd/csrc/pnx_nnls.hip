@@ -15,9 +15,14 @@
 //     leaving column k: Givens rotations on adjacent rows of M (column k removed) that annihilate M[:,k].
 //     Same selection rule, 0.01 independence test, ztest rejection, alpha interpolation, round-off clean-up
 //     loop and `iteration == maxiter` failure as Lawson-Hanson / SciPy 1.15 -> identical iteration counts.
-//   * Rows 0..63 of M live in LDS (packed lower triangle, 16.6 KB per wave; triangular-number row offsets make
-//     the row-wise ds_read_b64 conflict free), rows >= 64 in a per-wave HBM/L2 scratch.
-//   * G (n_bins^2 fp64 = 0.5 MB) and B stay L2 resident; the dual update streams p columns of G per iteration.
+//   * The kernel is latency bound per wave (throughput scales linearly with resident waves), so the per-voxel
+//     on-chip footprint is what matters: ONLY the first 56 rows of M live in LDS (packed lower triangle,
+//     12.8 KB per wave -> 12 waves per CU; triangular-number row offsets keep row-wise ds_read_b64 conflict
+//     free); rows >= 56 go to a per-wave L2/HBM scratch and are always touched row-contiguously.  Every
+//     position-indexed vector (q, x, z, g, l, rotation coefficients, position -> bin map) lives in registers,
+//     4 positions per lane, and is broadcast with v_readlane / moved with DPP instead of LDS round trips.
+//   * G (n_bins x 256 fp64 = 0.5 MB, zero padded) and B stay L2 resident; the dual update streams p rows of G per
+//     iteration, two 16-byte loads per lane and row, 8 rows in flight.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -30,10 +35,12 @@ namespace pnx {
 
 constexpr int kW = 64;
 constexpr int kSlots = kNnlsMaxBins / kW;  // 4
-constexpr int kLdsRows = 64;
-constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;                         // 2080 doubles
-constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;      // doubles per wave
+constexpr int kLdsRows = 56;               // rows of M kept in LDS (<= 64)
+constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
+constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
 constexpr int kNone = 1 << 30;
+constexpr int kGBatch = 8;  // rows of G in flight per lane in the dual update
+static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
 struct NnlsArgs {
     const double *y;
@@ -41,9 +48,9 @@ struct NnlsArgs {
     double *rnorm;
     int8_t *status;
     int32_t *iters;
-    const double *G;
-    const double *B;
-    const double *RT;
+    const double *G;   // (n_bins, 256) zero padded
+    const double *Bp;  // (n_meas, 256) zero padded
+    const double *RT;  // (n_bins, n_reg)
     double *Mglob;
     unsigned long long *queue;
     long long n_vox;
@@ -52,8 +59,9 @@ struct NnlsArgs {
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
 
-// Cross-lane reductions on the DPP data path (row_shr 1/2/4/8, row_bcast 15/31): a handful of VALU ops with
-// register-file latency instead of 12 ds_bpermute round trips through the LDS crossbar per fp64 reduction.
+// ---- cross-lane primitives ----------------------------------------------------------------------
+// DPP (row_shr 1/2/4/8, row_bcast 15/31): a handful of VALU ops with register-file latency instead of a dozen
+// ds_bpermute round trips per fp64 reduction.
 template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ inline double dpp_mov(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int olo = ZERO_FILL ? 0 : lo, ohi = ZERO_FILL ? 0 : hi;
@@ -66,8 +74,13 @@ template <int CTRL, int ROW_MASK> __device__ inline int dpp_mov_i(int v) {
 }
 constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118, kBc15 = 0x142, kBc31 = 0x143;
 
+// v_readlane of a double; `l` must be wave-uniform
+__device__ inline double rl(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 // inclusive prefix sum over the 64 lanes (lane 63 holds the total)
-__device__ inline double wave_incl_scan(double v, int) {
+__device__ inline double wave_incl_scan(double v) {
     v += dpp_mov<kShr1, 0xf, true>(v);
     v += dpp_mov<kShr2, 0xf, true>(v);
     v += dpp_mov<kShr4, 0xf, true>(v);
@@ -76,12 +89,7 @@ __device__ inline double wave_incl_scan(double v, int) {
     v += dpp_mov<kBc31, 0xc, true>(v);
     return v;
 }
-__device__ inline double bcast_lane63(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline double wave_sum(double v) { return bcast_lane63(wave_incl_scan(v, 0)); }
+__device__ inline double wave_sum(double v) { return rl(wave_incl_scan(v), 63); }
 __device__ inline double wave_max(double v) {
     v = fmax(v, dpp_mov<kShr1, 0xf, false>(v));
     v = fmax(v, dpp_mov<kShr2, 0xf, false>(v));
@@ -89,7 +97,7 @@ __device__ inline double wave_max(double v) {
     v = fmax(v, dpp_mov<kShr8, 0xf, false>(v));
     v = fmax(v, dpp_mov<kBc15, 0xa, false>(v));
     v = fmax(v, dpp_mov<kBc31, 0xc, false>(v));
-    return bcast_lane63(v);
+    return rl(v, 63);
 }
 __device__ inline double wave_min(double v) { return -wave_max(-v); }
 __device__ inline int wave_min_i(int v) {
@@ -103,36 +111,85 @@ __device__ inline int wave_min_i(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1} so that one row of G (leading dimension 256,
-// zero padded) is fetched with two 16-byte loads per lane.
+// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1}: one row of G or B is two 16-byte loads per lane.
 __device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
 
-// Column pass over the packed lower-triangular M: out[s] (k = lane + 64 s) = sum_{i >= k} v[i] * M[i][k].
-// v is an LDS vector (broadcast reads).  Two vectors at once (va, vb) so one sweep of M serves both.
+// ---- position-indexed register vectors (position i lives in lane i & 63, slot i >> 6) --------------
+template <int S> struct SlotTag { static constexpr int value = S; };
+// f(i, SlotTag<S>) for every position i in [lo, hi), slot known at compile time
+template <int S, int UNROLL, class F> __device__ inline void pos_range(int lo, int hi, F &&f) {
+    const int a = lo > kW * S ? lo : kW * S;
+    const int b = hi < kW * S + kW ? hi : kW * S + kW;
+#pragma unroll UNROLL
+    for (int i = a; i < b; ++i) f(i, SlotTag<S>{});
+}
+template <int UNROLL, class F> __device__ inline void for_pos(int lo, int hi, F &&f) {
+    pos_range<0, UNROLL>(lo, hi, f);
+    if (hi > kW) pos_range<1, UNROLL>(lo, hi, f);
+    if (hi > 2 * kW) pos_range<2, UNROLL>(lo, hi, f);
+    if (hi > 3 * kW) pos_range<3, UNROLL>(lo, hi, f);
+}
+// write v at (uniform) position pos
+__device__ inline void put(double (&a)[kSlots], int pos, double v, int lane) {
+    if (lane == (pos & 63)) {
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+            if ((pos >> 6) == s) a[s] = v;
+    }
+}
+__device__ inline void put_i(int (&a)[kSlots], int pos, int v, int lane) {
+    if (lane == (pos & 63)) {
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+            if ((pos >> 6) == s) a[s] = v;
+    }
+}
+// position i receives the value of position i + 1 (the last position receives garbage)
+__device__ inline void shift_down(const double (&a)[kSlots], double (&out)[kSlots], int lane) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        double v = __shfl_down(a[s], 1);
+        const double nxt0 = (s + 1 < kSlots) ? rl(a[s + 1 < kSlots ? s + 1 : s], 0) : 0.0;
+        out[s] = (lane == 63) ? nxt0 : v;
+    }
+}
+__device__ inline void shift_down_i(const int (&a)[kSlots], int (&out)[kSlots], int lane) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        int v = __shfl_down(a[s], 1);
+        const int nxt0 = (s + 1 < kSlots) ? __builtin_amdgcn_readlane(a[s + 1 < kSlots ? s + 1 : s], 0) : 0;
+        out[s] = (lane == 63) ? nxt0 : v;
+    }
+}
+
+// out[s] (k = lane + 64 s) = sum_{i >= k} va_i * M[i][k]  (and the same with vb when TWO): one sweep over the
+// packed lower-triangular M, every row read contiguously; va_i / vb_i are broadcast with v_readlane.
 template <bool TWO>
-__device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int lane, const double *va,
-                                const double *vb, double (&oa)[kSlots], double (&ob)[kSlots]) {
+__device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int lane, const double (&va)[kSlots],
+                                const double (&vb)[kSlots], double (&oa)[kSlots], double (&ob)[kSlots]) {
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
         oa[s] = 0;
         ob[s] = 0;
     }
     const int p_lds = p < kLdsRows ? p : kLdsRows;
+#pragma unroll 8
     for (int i = 0; i < p_lds; ++i) {
-        const double a = va[i];
-        const double b = TWO ? vb[i] : 0.0;
+        const double a = rl(va[0], i);
+        const double b = TWO ? rl(vb[0], i) : 0.0;
         if (lane <= i) {
             const double m = Mlds[tri(i) + lane];
             oa[0] += a * m;
             if (TWO) ob[0] += b * m;
         }
     }
-    for (int i = kLdsRows; i < p; ++i) {
-        const double a = va[i];
-        const double b = TWO ? vb[i] : 0.0;
+    for_pos<4>(kLdsRows, p, [&](int i, auto S) {
+        constexpr int si = decltype(S)::value;
+        const double a = rl(va[si], i & 63);
+        const double b = TWO ? rl(vb[si], i & 63) : 0.0;
         const double *row = Mg + (tri(i) - kLdsTri);
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s <= si; ++s) {
             const int k = lane + kW * s;
             if (k <= i) {
                 const double m = row[k];
@@ -140,17 +197,21 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
                 if (TWO) ob[s] += b * m;
             }
         }
-    }
+    });
 }
 
+#ifdef PNX_NNLS_STAMP
+#define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
-    extern __shared__ double sm[];
-    double *Mlds = sm;                     // kLdsTri
-    double *qv = sm + kLdsTri;             // q = M (A^T y)_P, by position
-    double *xv = qv + kNnlsMaxBins;        // x on the passive set, by position
-    double *t1 = xv + kNnlsMaxBins;        // scratch vectors
-    double *t2 = t1 + kNnlsMaxBins;
-    unsigned short *pidx = (unsigned short *)(t2 + kNnlsMaxBins);  // position -> bin
+#ifdef PNX_NNLS_STAMP
+    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M
     const int lane = threadIdx.x;
     double *Mg = A.Mglob + (size_t)blockIdx.x * kGlobTri;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
@@ -165,52 +226,65 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
         const long long vox = (long long)vq;
         const double *yv = A.y + (size_t)vox * nm;
 
-        // ---- load y, A^T y
+        // ---- y (by measurement: lane k & 63, slot k >> 6), A^T y = B^T y (by bin)
+        double yreg[2] = {0.0, 0.0};
         bool finite = true;
         double yn2 = 0;
-        __syncthreads();
-        for (int k = lane; k < nm; k += kW) {
-            const double v = yv[k];
-            t1[k] = v;
-            finite = finite && isfinite(v);
-            yn2 += v * v;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = lane + kW * s;
+            if (k < nm) {
+                yreg[s] = yv[k];
+                finite = finite && isfinite(yreg[s]);
+                yn2 += yreg[s] * yreg[s];
+            }
         }
         yn2 = wave_sum(yn2);
         finite = __all(finite ? 1 : 0) != 0;
-        __syncthreads();
-        double aty[kSlots], w[kSlots], z[kSlots];
-        bool inP[kSlots];
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
-            const int j = binof(lane, s);
-            double acc = 0;
-            if (j < n && finite)
-                for (int k = 0; k < nm; ++k) acc += A.B[(size_t)k * n + j] * t1[k];
-            aty[s] = acc;
-            inP[s] = false;
-            z[s] = 0;
+        double aty[kSlots] = {0, 0, 0, 0}, w[kSlots], z[kSlots] = {0, 0, 0, 0};
+        bool inP[kSlots] = {false, false, false, false};
+        if (finite) {
+#pragma unroll 4
+            for (int k = 0; k < nm; ++k) {
+                const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
+                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
+                const double2 b0 = *reinterpret_cast<const double2 *>(br);
+                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
+                aty[0] += b0.x * yk;
+                aty[1] += b0.y * yk;
+                aty[2] += b1.x * yk;
+                aty[3] += b1.y * yk;
+            }
         }
+        // position-indexed state
+        double q[kSlots] = {0, 0, 0, 0}, x[kSlots] = {0, 0, 0, 0};
+        int pidx[kSlots] = {0, 0, 0, 0};
         int p = 0, iteration = 0, status = finite ? 1 : -2;
+        STAMP(0);
 
         while (status == 1 && p < n && p < m_total) {
-            // ---- dual w = A^T y - G[:,P] x_P on the zero set
+            // ---- dual w = A^T y - G[:,P] x_P on the zero set: p rows of G (L2 resident), kGBatch in flight
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
-            // p rows of G (L2 resident), 8 in flight: the rows are independent, only the four accumulators chain
-            for (int pos0 = 0; pos0 < p; pos0 += 8) {
-                double2 ga[8], gb[8];
-                double xs[8];
+            for (int pos0 = 0; pos0 < p; pos0 += kGBatch) {
+                double2 ga[kGBatch], gb[kGBatch];
+                double xs[kGBatch];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < kGBatch; ++u) {
                     const int pos = pos0 + u < p ? pos0 + u : p - 1;
-                    const int col = __builtin_amdgcn_readfirstlane((int)pidx[pos]);
-                    xs[u] = pos0 + u < p ? xv[pos] : 0.0;
+                    const int sl = pos >> 6, ll_ = pos & 63;
+                    const int col = sl == 0 ? __builtin_amdgcn_readlane(pidx[0], ll_)
+                                  : sl == 1 ? __builtin_amdgcn_readlane(pidx[1], ll_)
+                                  : sl == 2 ? __builtin_amdgcn_readlane(pidx[2], ll_)
+                                            : __builtin_amdgcn_readlane(pidx[3], ll_);
+                    const double xv = sl == 0 ? rl(x[0], ll_) : sl == 1 ? rl(x[1], ll_) : sl == 2 ? rl(x[2], ll_) : rl(x[3], ll_);
+                    xs[u] = pos0 + u < p ? xv : 0.0;
                     const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
                     ga[u] = *reinterpret_cast<const double2 *>(gc);
                     gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < kGBatch; ++u) {
                     w[0] -= ga[u].x * xs[u];
                     w[1] -= ga[u].y * xs[u];
                     w[2] -= gb[u].x * xs[u];
@@ -220,6 +294,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
 #pragma unroll
             for (int s = 0; s < kSlots; ++s)
                 if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
+            STAMP(1);
 
             bool accepted = false;
             int jmax = 0;
@@ -231,44 +306,55 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) best = fmax(best, w[s]);
                 best = wave_max(best);
+                if (!(best > 0)) break;  // KKT satisfied
                 int bj = kNone;
 #pragma unroll
                 for (int s = kSlots - 1; s >= 0; --s)
                     if (w[s] == best) bj = binof(lane, s);
-                bj = wave_min_i(bj);  // ties: lowest bin
-                if (!(best > 0)) break;  // KKT satisfied
-                jmax = bj;
-                // ---- g = G[P, jmax] -> t1 ; l = M g
-                __syncthreads();
-                for (int pos = lane; pos < p; pos += kW) t1[pos] = A.G[(size_t)jmax * kNnlsMaxBins + pidx[pos]];
-                __syncthreads();
-                const double Gjj = A.G[(size_t)jmax * kNnlsMaxBins + jmax];
+                jmax = wave_min_i(bj);
+                // ---- g = G[P, jmax] (by position), l = M g
+                const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
+                double g[kSlots];
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) g[s] = (lane + kW * s < p) ? grow[pidx[s]] : 0.0;
+                const double Gjj = grow[jmax];
                 double atyj;
                 {
                     const int ol = (jmax & 127) >> 1, os = ((jmax >> 7) << 1) | (jmax & 1);  // owner lane / slot
                     const double av = os == 0 ? aty[0] : (os == 1 ? aty[1] : (os == 2 ? aty[2] : aty[3]));
-                    atyj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(av), ol),
-                                            __builtin_amdgcn_readlane(__double2loint(av), ol));
+                    atyj = rl(av, ol);
                 }
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) l[s] = 0;
+                {
+                    // LDS rows as a column sweep: uniform k, lane i accumulates M[i][k] g_k for i >= k
+                    const int plim = p < kLdsRows ? p : kLdsRows;
+                    const double *row0 = Mlds + tri(lane < plim ? lane : 0);
+#pragma unroll 8
+                    for (int k = 0; k < plim; ++k) {
+                        const double gk = rl(g[0], k);
+                        if (lane >= k && lane < plim) l[0] += row0[k] * gk;
+                    }
+                }
+                // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
+                for_pos<2>(kLdsRows, p, [&](int i, auto S) {
+                    constexpr int si = decltype(S)::value;
+                    const double *row = Mg + (tri(i) - kLdsTri);
+                    double part = 0;
+#pragma unroll
+                    for (int s = 0; s <= si; ++s) {
+                        const int k = lane + kW * s;
+                        if (k <= i) part += row[k] * g[s];
+                    }
+                    const double li = wave_sum(part);
+                    if (lane == (i & 63)) l[si] = li;
+                });
                 double ll = 0, lq = 0;
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
-                    l[s] = 0;
-                    const int i = lane + kW * s;
-                    if (kW * s < p) {
-                        if (i < p) {
-                            double acc = 0;
-                            if (s == 0) {
-                                const double *row = Mlds + tri(i);
-                                for (int k = 0; k <= i; ++k) acc += row[k] * t1[k];
-                            } else {
-                                const double *row = Mg + (tri(i) - kLdsTri);
-                                for (int k = 0; k <= i; ++k) acc += row[k] * t1[k];
-                            }
-                            l[s] = acc;
-                            ll += acc * acc;
-                            lq += acc * qv[i];
-                        }
+                    if (lane + kW * s < p) {
+                        ll += l[s] * l[s];
+                        lq += l[s] * q[s];
                     }
                 }
                 ll = wave_sum(ll);
@@ -293,22 +379,16 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                 for (int s = 0; s < kSlots; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;
             }
+            STAMP(2);
             if (!accepted) break;
 #ifdef PNX_NNLS_TRACE
             if (lane == 0 && blockIdx.x == 0) printf("A it=%d p=%d j=%d lam=%.17g qn=%.17g\n", iteration, p, jmax, lam, qn);
 #endif
 
             // ---- column jmax enters: new row of M and z = M^T q in one sweep over M
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
-                const int i = lane + kW * s;
-                if (i < p) t2[i] = l[s];
-            }
-            __syncthreads();
             {
                 double a1[kSlots], a2[kSlots];
-                col_pass<true>(Mlds, Mg, p, lane, t2, qv, a1, a2);
+                col_pass<true>(Mlds, Mg, p, lane, l, q, a1, a2);
                 const double inv = 1.0 / lam;
                 double *rowp = (p < kLdsRows) ? (Mlds + tri(p)) : (Mg + (tri(p) - kLdsTri));
 #pragma unroll
@@ -324,14 +404,13 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                     }
                     if (binof(lane, s) == jmax) inP[s] = true;
                 }
-                if (lane == 0) {
-                    qv[p] = qn;
-                    xv[p] = 0.0;
-                    pidx[p] = (unsigned short)jmax;
-                }
+                put(q, p, qn, lane);
+                put(x, p, 0.0, lane);
+                put_i(pidx, p, jmax, lane);
                 p += 1;
             }
             __syncthreads();
+            STAMP(3);
 
             // ---- inner loop: keep the passive-set solution feasible
             for (;;) {
@@ -346,8 +425,7 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                 for (int s = 0; s < kSlots; ++s) {
                     const int i = lane + kW * s;
                     if (i < p && z[s] <= 0) {
-                        const double xi = xv[i];
-                        const double T = -xi / (z[s] - xi);
+                        const double T = -x[s] / (z[s] - x[s]);
                         if (T < bestT) {
                             bestT = T;
                             bpos = i;
@@ -360,53 +438,41 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                     bpos = wave_min_i(bpos);  // ties: first position (Lawson-Hanson keeps the first minimum)
                     bestT = gmin;
                 }
-                __syncthreads();
                 if (bpos == kNone) {
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
-                        const int i = lane + kW * s;
-                        if (i < p) xv[i] = z[s];
-                    }
-                    __syncthreads();
+                    for (int s = 0; s < kSlots; ++s)
+                        if (lane + kW * s < p) x[s] = z[s];
                     break;
                 }
                 const double alpha = bestT;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    const int i = lane + kW * s;
-                    if (i < p) {
-                        const double xi = xv[i];
-                        xv[i] = xi + alpha * (z[s] - xi);
-                    }
-                }
-                __syncthreads();
+                for (int s = 0; s < kSlots; ++s)
+                    if (lane + kW * s < p) x[s] = x[s] + alpha * (z[s] - x[s]);
+                STAMP(4);
                 int jj = bpos;
                 for (;;) {
 #ifdef PNX_NNLS_TRACE
                     if (lane == 0 && blockIdx.x == 0) printf("R it=%d p=%d jj=%d alpha=%.17g\n", iteration, p, jj, alpha);
 #endif
-                    // ---- position jj leaves the passive set
+                    // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
+                    // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
                     double mv[kSlots], pre[kSlots];
                     double carry = 0;
 #pragma unroll
                     for (int s = 0; s < kSlots; ++s) {
                         const int i = lane + kW * s;
                         mv[s] = 0;
+                        pre[s] = carry;
                         if (kW * s < p) {
-                            if (i >= jj && i < p) {
-                                mv[s] = (s == 0) ? Mlds[tri(i) + jj] : Mg[tri(i) - kLdsTri + jj];
-                            }
-                            const double sc = wave_incl_scan(mv[s] * mv[s], lane);
+                            if (i >= jj && i < p) mv[s] = (i < kLdsRows) ? Mlds[tri(i) + jj] : Mg[tri(i) - kLdsTri + jj];
+                            const double sc = wave_incl_scan(mv[s] * mv[s]);
                             pre[s] = sc + carry;
-                            carry += bcast_lane63(sc);
-                            if (i < p) {
-                                t1[i] = pre[s];
-                                t2[i] = mv[s];
-                            }
-                        } else
-                            pre[s] = carry;
+                            carry += rl(sc, 63);
+                        }
                     }
-                    __syncthreads();
+                    double mnext[kSlots], prenext[kSlots];
+                    shift_down(mv, mnext, lane);
+                    shift_down(pre, prenext, lane);
                     double cs[kSlots], sn[kSlots];
 #pragma unroll
                     for (int s = 0; s < kSlots; ++s) {
@@ -415,25 +481,18 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                         sn[s] = 0.0;
                         if (i >= jj && i < p - 1) {
                             const double a = (i == jj) ? mv[s] : sqrt(pre[s]);  // first carried value keeps its sign
-                            const double b = t2[i + 1];
-                            const double r = sqrt(t1[i + 1]);
+                            const double b = mnext[s];
+                            const double r = sqrt(prenext[s]);
                             if (r > 0) {
                                 cs[s] = b / r;
                                 sn[s] = a / r;
                             }
                         }
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
-                        const int i = lane + kW * s;
-                        if (i < p) {
-                            t1[i] = cs[s];
-                            t2[i] = sn[s];
-                        }
-                    }
-                    const int bin_out = pidx[jj];
-                    __syncthreads();
+                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(pidx[0], jj & 63)
+                                      : jj < 2 * kW ? __builtin_amdgcn_readlane(pidx[1], jj & 63)
+                                      : jj < 3 * kW ? __builtin_amdgcn_readlane(pidx[2], jj & 63)
+                                                    : __builtin_amdgcn_readlane(pidx[3], jj & 63);
                     {
                         double car[kSlots];
                         const double *rowj = (jj < kLdsRows) ? (Mlds + tri(jj)) : (Mg + (tri(jj) - kLdsTri));
@@ -442,109 +501,114 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
                             const int c = lane + kW * s;
                             car[s] = (c < jj) ? rowj[c] : 0.0;
                         }
-                        double carq = qv[jj];
-                        for (int i = jj; i < p - 1; ++i) {
-                            const double c_ = t1[i], s_ = t2[i];
-                            const double qnx = qv[i + 1];
+                        double carq = jj < kW ? rl(q[0], jj & 63) : jj < 2 * kW ? rl(q[1], jj & 63)
+                                    : jj < 3 * kW ? rl(q[2], jj & 63) : rl(q[3], jj & 63);
+                        double qsh[kSlots];
+                        shift_down(q, qsh, lane);  // qsh[i] = q[i + 1]
+                        for_pos<2>(jj, p - 1, [&](int i, auto S) {
+                            constexpr int si = decltype(S)::value;
+                            const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
+                            const double qnx = rl(qsh[si], i & 63);
                             const double *rown = (i + 1 < kLdsRows) ? (Mlds + tri(i + 1)) : (Mg + (tri(i + 1) - kLdsTri));
                             double *rowo = (i < kLdsRows) ? (Mlds + tri(i)) : (Mg + (tri(i) - kLdsTri));
-                            double outv[kSlots];
 #pragma unroll
-                            for (int s = 0; s < kSlots; ++s) {
+                            for (int s = 0; s <= si; ++s) {
                                 const int c = lane + kW * s;
-                                outv[s] = 0;
-                                if (kW * s <= i && c <= i) {
+                                if (c <= i) {
                                     const double nxt = rown[c < jj ? c : c + 1];
-                                    outv[s] = c_ * car[s] - s_ * nxt;
+                                    const double outv = c_ * car[s] - s_ * nxt;
                                     car[s] = s_ * car[s] + c_ * nxt;
+                                    rowo[c] = outv;
                                 }
-                            }
-                            // row i+1 has been read by every lane before row i (<= i entries) is overwritten:
-                            // rows are distinct, so no ordering issue inside the step
-#pragma unroll
-                            for (int s = 0; s < kSlots; ++s) {
-                                const int c = lane + kW * s;
-                                if (kW * s <= i && c <= i) rowo[c] = outv[s];
                             }
                             const double oq = c_ * carq - s_ * qnx;
                             carq = s_ * carq + c_ * qnx;
-                            if (lane == 0) qv[i] = oq;
-                        }
+                            if (lane == (i & 63)) q[si] = oq;
+                        });
                     }
-                    __syncthreads();
                     // ---- drop position jj from x / pidx
-                    double xs[kSlots];
-                    unsigned short ps[kSlots];
+                    {
+                        double xsh[kSlots];
+                        int psh[kSlots];
+                        shift_down(x, xsh, lane);
+                        shift_down_i(pidx, psh, lane);
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
-                        const int i = lane + kW * s;
-                        xs[s] = 0;
-                        ps[s] = 0;
-                        if (i >= jj && i < p - 1) {
-                            xs[s] = xv[i + 1];
-                            ps[s] = pidx[i + 1];
+                        for (int s = 0; s < kSlots; ++s) {
+                            const int i = lane + kW * s;
+                            if (i >= jj && i < p - 1) {
+                                x[s] = xsh[s];
+                                pidx[s] = psh[s];
+                            }
+                            if (binof(lane, s) == bin_out) inP[s] = false;
                         }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
-                        const int i = lane + kW * s;
-                        if (i >= jj && i < p - 1) {
-                            xv[i] = xs[s];
-                            pidx[i] = ps[s];
-                        }
-                        if (binof(lane, s) == bin_out) inP[s] = false;
                     }
                     p -= 1;
                     __syncthreads();
-#ifdef PNX_NNLS_TRACE
-                    if (lane == 0 && blockIdx.x == 0 && iteration == 21) {
-                        for (int i = 0; i < p; ++i) printf("  q[%d]=%.15g Mii=%.15g Mi0=%.15g x=%.15g pidx=%d\n", i, qv[i], Mlds[tri(i)+i], Mlds[tri(i)], xv[i], (int)pidx[i]);
-                    }
-#endif
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
+                    for (int s = kSlots - 1; s >= 0; --s) {
                         const int i = lane + kW * s;
-                        if (i < p && xv[i] <= 0 && i < bad) bad = i;
+                        if (i < p && x[s] <= 0) bad = i;
                     }
                     bad = wave_min_i(bad);
                     if (bad == kNone) break;
                     jj = bad;
                 }
+                STAMP(5);
                 // ---- z = M^T q
                 {
                     double dummy[kSlots];
-                    col_pass<false>(Mlds, Mg, p, lane, qv, qv, z, dummy);
+                    col_pass<false>(Mlds, Mg, p, lane, q, q, z, dummy);
                 }
+                STAMP(6);
             }
         }
+        STAMP(7);
 
-        // ---- outputs
+        // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
+        double xb[kSlots] = {0, 0, 0, 0};
+        if (status == 1) {
+            for_pos<4>(0, p, [&](int i, auto S) {
+                constexpr int si = decltype(S)::value;
+                const int b = __builtin_amdgcn_readlane(pidx[si], i & 63);
+                const double xv = rl(x[si], i & 63);
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (binof(lane, s) == b) xb[s] = xv;
+            });
+        }
         double *cv = A.coeff + (size_t)vox * n;
-        __syncthreads();
-        for (int j = lane; j < n; j += kW) t1[j] = 0.0;
-        __syncthreads();
-        if (status == 1)
-            for (int pos = lane; pos < p; pos += kW) t1[pidx[pos]] = xv[pos];
-        __syncthreads();
-        for (int j = lane; j < n; j += kW) cv[j] = t1[j];
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int j = binof(lane, s);
+            if (j < n) cv[j] = xb[s];
+        }
         double rn;
         if (status == 1) {
-            // rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly (no ||y||^2 - ||q||^2 cancellation)
             double acc = 0;
-            for (int k = lane; k < nm; k += kW) {
-                double r = -yv[k];
-                for (int pos = 0; pos < p; ++pos) r += A.B[(size_t)k * n + pidx[pos]] * xv[pos];
-                acc += r * r;
+            for (int k = 0; k < nm; ++k) {
+                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
+                const double2 b0 = *reinterpret_cast<const double2 *>(br);
+                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
+                const double fit = wave_sum(b0.x * xb[0] + b0.y * xb[1] + b1.x * xb[2] + b1.y * xb[3]);
+                const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
+                if (lane == 0) acc += (fit - yk) * (fit - yk);
             }
-            for (int i = lane; i < nreg; i += kW) {
+            acc = rl(acc, 0);
+            double racc = 0;
+            for (int i0 = 0; i0 < nreg; i0 += kW) {
+                const int i = i0 + lane;
                 double r = 0;
-                for (int pos = 0; pos < p; ++pos) r += A.RT[(size_t)pidx[pos] * nreg + i] * xv[pos];
-                acc += r * r;
+                for_pos<4>(0, p, [&](int pos, auto S) {
+                    constexpr int si = decltype(S)::value;
+                    const int b = __builtin_amdgcn_readlane(pidx[si], pos & 63);
+                    const double xv = rl(x[si], pos & 63);
+                    if (i < nreg) r += A.RT[(size_t)b * nreg + i] * xv;
+                });
+                racc += r * r;
             }
-            rn = sqrt(wave_sum(acc));
+            rn = sqrt(acc + wave_sum(racc));
         } else
             rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
         if (lane == 0) {
@@ -552,7 +616,12 @@ __global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
             if (A.status) A.status[vox] = (int8_t)status;
             if (A.iters) A.iters[vox] = iteration;
         }
+        STAMP(8);
     }
+#ifdef PNX_NNLS_STAMP
+    if (lane == 0 && blockIdx.x == 7)
+        printf("STAMP setup=%llu w=%llu cand=%llu append=%llu alpha=%llu removal=%llu colpass2=%llu tail=%llu out=%llu\n", seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7], seg[8]);
+#endif
 }
 
 // ---- plan-time kernels ------------------------------------------------------------------------
@@ -580,7 +649,7 @@ __global__ void basis_kernel(const double *b, const double *bins, int nm, int n,
         if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-static size_t nnls_lds_bytes() { return sizeof(double) * (kLdsTri + 4 * kNnlsMaxBins) + sizeof(unsigned short) * kNnlsMaxBins; }
+static size_t nnls_lds_bytes() { return sizeof(double) * kLdsTri; }
 
 int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                    int device, int cus) {
@@ -593,11 +662,14 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     for (size_t i = 0; i < nb; ++i)
         if (!std::isfinite(basis[i])) return set_error(PNX_ERR_INVALID, "basis contains non-finite values");
     PNX_HIPN(hipMalloc(&P->B, nb * sizeof(double)));
+    PNX_HIPN(hipMalloc(&P->Bp, (size_t)n_meas * kNnlsMaxBins * sizeof(double)));
+    PNX_HIPN(hipMemset(P->Bp, 0, (size_t)n_meas * kNnlsMaxBins * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->RT, (nr ? nr : 1) * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->G, ng * sizeof(double)));
     PNX_HIPN(hipMemset(P->G, 0, ng * sizeof(double)));  // rows padded to 256 columns
     PNX_HIPN(hipMalloc(&P->queue, sizeof(unsigned long long)));
     PNX_HIPN(hipMemcpy(P->B, basis, nb * sizeof(double), hipMemcpyHostToDevice));
+    PNX_HIPN(hipMemcpy2D(P->Bp, kNnlsMaxBins * sizeof(double), basis, (size_t)n_bins * sizeof(double), (size_t)n_bins * sizeof(double), n_meas, hipMemcpyHostToDevice));
     if (nr) {
         std::vector<double> rt(nr);
         for (int i = 0; i < n_reg; ++i)
@@ -625,6 +697,7 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
 
 void nnls_plan_free(NnlsPlanData *P) {
     if (P->B) (void)hipFree(P->B);
+    if (P->Bp) (void)hipFree(P->Bp);
     if (P->RT) (void)hipFree(P->RT);
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
@@ -641,7 +714,7 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
     a.status = status_d;
     a.iters = iters_d;
     a.G = P->G;
-    a.B = P->B;
+    a.Bp = P->Bp;
     a.RT = P->RT;
     a.Mglob = P->Mglob;
     a.queue = P->queue;

@@ -13,6 +13,7 @@ struct NnlsPlanData {
     int cus = 0;
     int n_meas = 0, n_bins = 0, n_reg = 0;
     double *B = nullptr;      // (n_meas, n_bins) row-major: basis
+    double *Bp = nullptr;     // (n_meas, 256) zero padded copy (16-byte aligned rows for the kernel)
     double *RT = nullptr;     // (n_bins, n_reg)  row-major: reg transposed (column j of reg contiguous)
     double *G = nullptr;      // (n_bins, n_bins): A^T A = B^T B + reg^T reg, fp64
     double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
