@@ -16,13 +16,13 @@
 //     Same selection rule, 0.01 independence test, ztest rejection, alpha interpolation, round-off clean-up
 //     loop and `iteration == maxiter` failure as Lawson-Hanson / SciPy 1.15 -> identical iteration counts.
 //   * The kernel is latency bound per wave (throughput scales linearly with resident waves), so the per-voxel
-//     on-chip footprint is what matters: ONLY the first 56 rows of M live in LDS (packed lower triangle,
-//     12.8 KB per wave -> 12 waves per CU; triangular-number row offsets keep row-wise ds_read_b64 conflict
-//     free); rows >= 56 go to a per-wave L2/HBM scratch and are always touched row-contiguously.  Every
+//     on-chip footprint is what matters: ONLY the first 48 rows of M live in LDS (packed lower triangle,
+//     9.4 KB per wave, <= 128 VGPRs -> 16 waves per CU; triangular-number row offsets keep ds_read_b64 conflict
+//     free); rows >= 48 go to a per-wave L2/HBM scratch and are always touched row-contiguously.  Every
 //     position-indexed vector (q, x, z, g, l, rotation coefficients, position -> bin map) lives in registers,
 //     4 positions per lane, and is broadcast with v_readlane / moved with DPP instead of LDS round trips.
 //   * G (n_bins x 256 fp64 = 0.5 MB, zero padded) and B stay L2 resident; the dual update streams p rows of G per
-//     iteration, two 16-byte loads per lane and row, 8 rows in flight.
+//     iteration, two 16-byte loads per lane and row, 4 rows in flight.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -35,11 +35,11 @@ namespace pnx {
 
 constexpr int kW = 64;
 constexpr int kSlots = kNnlsMaxBins / kW;  // 4
-constexpr int kLdsRows = 56;               // rows of M kept in LDS (<= 64)
+constexpr int kLdsRows = 48;               // rows of M kept in LDS (<= 64)
 constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
 constexpr int kNone = 1 << 30;
-constexpr int kGBatch = 8;  // rows of G in flight per lane in the dual update
+constexpr int kGBatch = 4;  // rows of G in flight per lane in the dual update
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
 struct NnlsArgs {
@@ -206,7 +206,7 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #define STAMP(k) do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(64) nnls_kernel(const NnlsArgs A) {
+__global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
