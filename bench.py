@@ -94,7 +94,7 @@ class CurvefitLeg:
         from pyneapple_amd import synth
 
         cores = host_cores()
-        n = 8192 * cores
+        n = 32768 * cores  # ~10-20 s of CPU work on 16 threads
         b, y, _ = synth.make_numpy(self.model, n, self.n_b, sigma=0.01)
         O.curvefit(self.model, b, y[:256], self.p0, self.lo, self.hi, n_threads=cores)  # warm-up / build
         t = time.perf_counter()
@@ -145,7 +145,7 @@ class NnlsLeg:
         from pyneapple_amd import synth
 
         cores = host_cores()
-        n = 96 * cores
+        n = 128 * cores
         _, y, _ = synth.make_numpy("tri_reduced", n, self.n_b, sigma=0.01, scale=1000.0)
         O.nnls(self.basis, self.reg, y[:cores], self.cfg["max_iter"], n_threads=cores)
         t = time.perf_counter()
@@ -179,6 +179,42 @@ def timed(leg, steps, warmup, world, dist, torch):
 
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
     return dt, kernel_ms
+
+
+def sweep_roofline(device, torch, n_vox_override=0, reps=10):
+    """The LM residual/Jacobian/normal-equation sweep as a standalone HBM-streaming kernel (pnx_sweep_f32),
+    triexp on the C3 volume: 232 algorithmic bytes per voxel-sweep against the HBM roofline."""
+    from pyneapple_amd import api, synth
+
+    model, n_b, shape = synth.WORKLOADS["triexp"]
+    n_vox = n_vox_override or int(np.prod(shape))
+    b, y64 = synth.make_torch(model, n_vox, n_b, device, sigma=0.01)
+    y = y64.float()
+    del y64
+    names, p0, _, _ = synth.shared_arrays(model)
+    n = len(names)
+    ntri = n * (n + 1) // 2
+    params = torch.tensor(p0, dtype=torch.float32, device=device)[:, None].repeat(1, n_vox).contiguous()
+    params *= 1.0 + 0.05 * torch.rand_like(params)
+    cost = torch.empty(n_vox, dtype=torch.float32, device=device)
+    g = torch.empty((n, n_vox), dtype=torch.float32, device=device)
+    h = torch.empty((ntri, n_vox), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    bytes_per = (n_b + n + ntri + n + 1) * 4
+    ach = bytes_per * n_vox / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "sweep_kernel<tri_reduced,f32>", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_voxel": bytes_per,
+            "kernel_ms_avg": ms, "voxel_sweeps_per_s": n_vox / (ms * 1e-3), "dtype": "f32"}
 
 
 def main():
@@ -246,6 +282,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec
+    if args.workload == "triexp" and not args.no_secondary:
+        out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -169,3 +169,14 @@ def nnls_basis(b, bins, device=0):
     out = np.empty((b.size, bins.size))
     check(load().pnx_nnls_basis(b.size, ptr(b), bins.size, ptr(bins), ptr(out), device))
     return out
+
+
+def sweep_device(model, n_vox, b, y, params, cost, g, jtj, device, stream=None):
+    """Enqueue one residual/Jacobian/normal-equation sweep on HBM-resident torch tensors (f32 or f64)."""
+    import torch
+
+    f64 = y.dtype == torch.float64
+    b = np.ascontiguousarray(b, np.float64 if f64 else np.float32)
+    fn = load().pnx_sweep_f64 if f64 else load().pnx_sweep_f32
+    check(fn(MODEL_IDS[model], int(n_vox), int(b.size), ptr(b), ptr(y), ptr(params), ptr(cost), ptr(g), ptr(jtj),
+             int(device), stream))

@@ -390,15 +390,4 @@ int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, 
     return nnls_build_basis(n_meas, b, n_bins, bins, basis);
 }
 
-int pnx_sweep_f32(int model, int64_t n_vox, int n_b, const float *b_host, const float *y, const float *params,
-                  float *out_cost, float *out_g, float *out_jtj, int device, void *stream) {
-    (void)model; (void)n_vox; (void)n_b; (void)b_host; (void)y; (void)params; (void)out_cost; (void)out_g; (void)out_jtj; (void)device; (void)stream;
-    return set_error(PNX_ERR_UNSUPPORTED, "pnx_sweep_f32 is not built yet");
-}
-int pnx_sweep_f64(int model, int64_t n_vox, int n_b, const double *b_host, const double *y, const double *params,
-                  double *out_cost, double *out_g, double *out_jtj, int device, void *stream) {
-    (void)model; (void)n_vox; (void)n_b; (void)b_host; (void)y; (void)params; (void)out_cost; (void)out_g; (void)out_jtj; (void)device; (void)stream;
-    return set_error(PNX_ERR_UNSUPPORTED, "pnx_sweep_f64 is not built yet");
-}
-
 }  // extern "C"

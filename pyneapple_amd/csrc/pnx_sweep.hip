@@ -1,0 +1,237 @@
+// pnx_sweep.hip -- residual / Jacobian / normal-equation sweep at given parameters (one LM inner-loop
+// pass as a standalone, HBM-streaming kernel), fp32 and fp64.
+//
+// For every voxel: read the signal row (n_b values) and the parameter vector (n_all), write
+//   cost = 0.5 * ||model - y||^2,   g = J^T r  (n_all),   upper triangle of J^T J  (n_all (n_all + 1) / 2)
+// with the analytic Jacobian of the reference's models (models/{monoexp,biexp,triexp}.py jacobian()).
+// Algorithmic bytes per voxel-sweep: (n_b + n_all) in, (n_tri + n_all + 1) out, times sizeof(T);
+// triexp fp32: (32 + 5 + 15 + 5 + 1) * 4 = 232 B.
+//
+// Mapping: one lane per voxel; a wave stages its 64 x n_b signal tile through LDS with fully coalesced
+// 16-byte loads (the (n_vox, n_b) matrix is row-major, a lane-per-row global read would touch 64 cache lines per
+// instruction), rows padded by one element so the per-lane row reads are bank-conflict free; parameters and
+// all outputs are parameter-major (k, n_vox), i.e. coalesced across the wavefront axis.
+#include <hip/hip_runtime.h>
+
+#include "pnx_curvefit_kernel.hpp"
+#include "pnx_internal.hpp"
+
+namespace pnx {
+
+template <typename T> struct SweepArgs {
+    const T *y;       // (n_vox, n_b)
+    const T *params;  // (n_all, n_vox)
+    T *cost;          // (n_vox)
+    T *g;             // (n_all, n_vox)
+    T *jtj;           // (n_tri, n_vox)
+    long long n_vox;
+    int n_b;
+    T b[kMaxB];
+};
+
+template <typename T> __device__ inline T fast_exp(T x);
+template <> __device__ inline float fast_exp<float>(float x) { return __expf(x); }  // v_exp_f32 (native 2^x)
+template <> __device__ inline double fast_exp<double>(double x) { return exp(x); }
+
+// Model<MODEL> works on doubles; a thin generic restatement of signal/jac for T (same formulas)
+template <int MODEL, typename T> struct ModelT {
+    using M = Model<MODEL>;
+    static constexpr int NALL = M::NALL, NC = M::NC;
+    __device__ static void eval(const T *p, T bb, T &sig, T *ja) {
+        T E[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) E[c] = fast_exp<T>(-bb * p[M::dpos(c)]);
+        if constexpr (MODEL == 0) {
+            sig = p[0] * E[0];
+            ja[0] = E[0];
+            ja[1] = -bb * p[0] * E[0];
+        } else if constexpr (MODEL == 1) {
+            sig = p[0] * E[0] + (1 - p[0]) * E[1];
+            ja[0] = E[0] - E[1];
+            ja[1] = -bb * p[0] * E[0];
+            ja[2] = -bb * (1 - p[0]) * E[1];
+        } else if constexpr (MODEL == 2) {
+            const T inner = p[0] * E[0] + (1 - p[0]) * E[1];
+            sig = p[3] * inner;
+            ja[0] = p[3] * (E[0] - E[1]);
+            ja[1] = -bb * p[3] * p[0] * E[0];
+            ja[2] = -bb * p[3] * (1 - p[0]) * E[1];
+            ja[3] = inner;
+        } else if constexpr (MODEL == 3) {
+            sig = p[0] * E[0] + p[2] * E[1];
+            ja[0] = E[0];
+            ja[1] = -bb * p[0] * E[0];
+            ja[2] = E[1];
+            ja[3] = -bb * p[2] * E[1];
+        } else if constexpr (MODEL == 4) {
+            const T f3 = 1 - p[0] - p[2];
+            sig = p[0] * E[0] + p[2] * E[1] + f3 * E[2];
+            ja[0] = E[0] - E[2];
+            ja[1] = -bb * p[0] * E[0];
+            ja[2] = E[1] - E[2];
+            ja[3] = -bb * p[2] * E[1];
+            ja[4] = -bb * f3 * E[2];
+        } else if constexpr (MODEL == 5) {
+            const T f3 = 1 - p[0] - p[2];
+            const T inner = p[0] * E[0] + p[2] * E[1] + f3 * E[2];
+            sig = p[5] * inner;
+            ja[0] = p[5] * (E[0] - E[2]);
+            ja[1] = -bb * p[5] * p[0] * E[0];
+            ja[2] = p[5] * (E[1] - E[2]);
+            ja[3] = -bb * p[5] * p[2] * E[1];
+            ja[4] = -bb * p[5] * f3 * E[2];
+            ja[5] = inner;
+        } else {
+            sig = p[0] * E[0] + p[2] * E[1] + p[4] * E[2];
+            ja[0] = E[0];
+            ja[1] = -bb * p[0] * E[0];
+            ja[2] = E[1];
+            ja[3] = -bb * p[2] * E[1];
+            ja[4] = E[2];
+            ja[5] = -bb * p[4] * E[2];
+        }
+    }
+};
+
+template <int MODEL, typename T>
+__global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
+    using MT = ModelT<MODEL, T>;
+    constexpr int NALL = MT::NALL;
+    constexpr int NTRI = NALL * (NALL + 1) / 2;
+    constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte load
+    extern __shared__ unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+    const int n_b = A.n_b;
+    const int stride = n_b + 1;  // padded row: lane-per-row reads hit 64 different banks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T *tile = smem + kMaxB + (size_t)wave * kWave * stride;
+    T *bsh = smem;
+    for (int i = threadIdx.x; i < n_b; i += blockDim.x) bsh[i] = A.b[i];
+    __syncthreads();
+    const long long n_tiles = (A.n_vox + kWave - 1) / kWave;
+    const long long tiles_per_block = blockDim.x >> 6;
+    for (long long t = (long long)blockIdx.x * tiles_per_block + wave; t < n_tiles; t += (long long)gridDim.x * tiles_per_block) {
+        const long long v0 = t * kWave;
+        const int nv = (A.n_vox - v0) < kWave ? (int)(A.n_vox - v0) : kWave;
+        // ---- coalesced tile load: the tile is one contiguous block of nv * n_b elements
+        const T *src = A.y + (size_t)v0 * n_b;
+        const int total = nv * n_b;
+        if ((n_b % VEC) == 0) {
+            for (int e = lane * VEC; e < total; e += kWave * VEC) {
+                T tmp[VEC];
+                *reinterpret_cast<float4 *>(tmp) = *reinterpret_cast<const float4 *>(src + e);
+                const int v = e / n_b, i = e - v * n_b;
+#pragma unroll
+                for (int u = 0; u < VEC; ++u) tile[v * stride + i + u] = tmp[u];
+            }
+        } else {
+            for (int e = lane; e < total; e += kWave) {
+                const int v = e / n_b, i = e - v * n_b;
+                tile[v * stride + i] = src[e];
+            }
+        }
+        const long long vox = v0 + lane;
+        const bool live = lane < nv;
+        T p[NALL];
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) p[k] = live ? A.params[(size_t)k * A.n_vox + vox] : T(0);
+        T cost = 0, g[NALL], H[NTRI];
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) g[k] = 0;
+#pragma unroll
+        for (int k = 0; k < NTRI; ++k) H[k] = 0;
+        const T *row = tile + lane * stride;
+#pragma unroll 4
+        for (int i = 0; i < n_b; ++i) {
+            T sig, ja[NALL];
+            MT::eval(p, bsh[i], sig, ja);
+            const T r = sig - row[i];
+            cost += r * r;
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < NALL; ++a) {
+                g[a] += ja[a] * r;
+#pragma unroll
+                for (int c = a; c < NALL; ++c) H[q++] += ja[a] * ja[c];
+            }
+        }
+        if (live) {
+            A.cost[vox] = T(0.5) * cost;
+#pragma unroll
+            for (int k = 0; k < NALL; ++k) A.g[(size_t)k * A.n_vox + vox] = g[k];
+#pragma unroll
+            for (int k = 0; k < NTRI; ++k) A.jtj[(size_t)k * A.n_vox + vox] = H[k];
+        }
+    }
+}
+
+template <int MODEL, typename T>
+static int launch_sweep(const SweepArgs<T> &a, int cus, hipStream_t st) {
+    const int block = 256;
+    const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (a.n_b + 1));
+    const long long n_tiles = (a.n_vox + kWave - 1) / kWave;
+    long long want = (n_tiles + 3) / 4;
+    long long cap = (long long)cus * 8;  // memory-bound: ~2048 blocks, grid-stride the rest
+    int grid = (int)(want < cap ? want : cap);
+    if (grid < 1) grid = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute((const void *)sweep_kernel<MODEL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
+        attr_set = true;
+    }
+    if (shmem > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", a.n_b);
+    hipLaunchKernelGGL((sweep_kernel<MODEL, T>), dim3(grid), dim3(block), shmem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PNX_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
+    return PNX_OK;
+}
+
+template <typename T>
+static int sweep_impl(int model, int64_t n_vox, int n_b, const T *b_host, const T *y, const T *params, T *out_cost,
+                      T *out_g, T *out_jtj, int device, void *stream) {
+    if (model < 0 || model > 6) return set_error(PNX_ERR_INVALID, "unknown model %d", model);
+    if (n_b < 1 || n_b > kMaxB) return set_error(PNX_ERR_INVALID, "n_b=%d out of range", n_b);
+    if (n_vox < 0 || !b_host || (n_vox && (!y || !params || !out_cost || !out_g || !out_jtj)))
+        return set_error(PNX_ERR_INVALID, "NULL pointer");
+    if (n_vox == 0) return PNX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(PNX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return set_error(PNX_ERR_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(PNX_ERR_HIP, "hipGetDeviceProperties failed");
+    SweepArgs<T> a;
+    a.y = y;
+    a.params = params;
+    a.cost = out_cost;
+    a.g = out_g;
+    a.jtj = out_jtj;
+    a.n_vox = n_vox;
+    a.n_b = n_b;
+    for (int i = 0; i < n_b; ++i) a.b[i] = b_host[i];
+    hipStream_t st = (hipStream_t)stream;
+    const int cus = prop.multiProcessorCount;
+    switch (model) {
+    case 0: return launch_sweep<0, T>(a, cus, st);
+    case 1: return launch_sweep<1, T>(a, cus, st);
+    case 2: return launch_sweep<2, T>(a, cus, st);
+    case 3: return launch_sweep<3, T>(a, cus, st);
+    case 4: return launch_sweep<4, T>(a, cus, st);
+    case 5: return launch_sweep<5, T>(a, cus, st);
+    default: return launch_sweep<6, T>(a, cus, st);
+    }
+}
+
+}  // namespace pnx
+
+extern "C" {
+int pnx_sweep_f32(int model, int64_t n_vox, int n_b, const float *b_host, const float *y, const float *params,
+                  float *out_cost, float *out_g, float *out_jtj, int device, void *stream) {
+    return pnx::sweep_impl<float>(model, n_vox, n_b, b_host, y, params, out_cost, out_g, out_jtj, device, stream);
+}
+int pnx_sweep_f64(int model, int64_t n_vox, int n_b, const double *b_host, const double *y, const double *params,
+                  double *out_cost, double *out_g, double *out_jtj, int device, void *stream) {
+    return pnx::sweep_impl<double>(model, n_vox, n_b, b_host, y, params, out_cost, out_g, out_jtj, device, stream);
+}
+}
