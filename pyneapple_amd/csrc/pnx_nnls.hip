@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "pnx_internal.hpp"
@@ -40,6 +41,7 @@ constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
 constexpr int kNone = 1 << 30;
 constexpr int kGBatch = 4;  // rows of G in flight per lane in the dual update
+constexpr int64_t kAtyChunk = 1 << 20;  // voxels per MFMA Gram step / active-set launch pair
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
 struct NnlsArgs {
@@ -51,6 +53,7 @@ struct NnlsArgs {
     const double *G;   // (n_bins, 256) zero padded
     const double *Bp;  // (n_meas, 256) zero padded
     const double *RT;  // (n_bins, n_reg)
+    const double *aty; // (n_vox, 256) = Y * Bp from the MFMA Gram step, or null (computed per wave on the VALU)
     double *Mglob;
     unsigned long long *queue;
     long long n_vox;
@@ -243,7 +246,15 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
         finite = __all(finite ? 1 : 0) != 0;
         double aty[kSlots] = {0, 0, 0, 0}, w[kSlots], z[kSlots] = {0, 0, 0, 0};
         bool inP[kSlots] = {false, false, false, false};
-        if (finite) {
+        if (finite && A.aty) {
+            const double *ar = A.aty + (size_t)vox * kNnlsMaxBins + 2 * lane;
+            const double2 a0 = *reinterpret_cast<const double2 *>(ar);
+            const double2 a1 = *reinterpret_cast<const double2 *>(ar + 128);
+            aty[0] = a0.x;
+            aty[1] = a0.y;
+            aty[2] = a1.x;
+            aty[3] = a1.y;
+        } else if (finite) {
 #pragma unroll 4
             for (int k = 0; k < nm; ++k) {
                 const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
@@ -624,6 +635,53 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
 #endif
 }
 
+// ---- Gram step on the matrix cores -----------------------------------------------------------------
+// ATY (n_vox, 256) = Y (n_vox, n_meas) * Bp (n_meas, 256) in fp64 on v_mfma_f64_16x16x4_f64 (the right-hand side
+// of every voxel's normal equations must be fp64: with an fp32 Gram the NNLS solution is off by O(1), SURVEY.md
+// section 7).  One wave owns a strip of 16 voxels x 256 bins: 16 column tiles x (n_meas / 4) MFMAs; Bp is staged
+// once per block in LDS ([k][256], fragment reads are 128-byte contiguous per k), Y fragments come straight from
+// L2/HBM (4 KB per strip).  Lane maps (cdna_hip_programming.md section 3): A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D: col = l & 15, row = (l >> 4) + 4 * reg.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+__global__ void __launch_bounds__(256) nnls_aty_mfma_kernel(const double *Y, const double *Bp, double *ATY,
+                                                            long long n_vox, int nm) {
+    extern __shared__ double bsm[];  // [kpad][256]
+    const int kpad = (nm + 3) & ~3;
+    for (int e = threadIdx.x; e < kpad * kNnlsMaxBins; e += blockDim.x)
+        bsm[e] = (e / kNnlsMaxBins) < nm ? Bp[e] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const long long n_strips = (n_vox + 15) / 16;
+    for (long long st = (long long)blockIdx.x * 4 + wave; st < n_strips; st += (long long)gridDim.x * 4) {
+        const long long v0 = st * 16;
+        const long long va = v0 + r16;
+        // A fragments for all k-steps: Y[v0 + r16][4 s + kq]
+        double afrag[kNnlsMaxMeas / 4];
+#pragma unroll
+        for (int s4 = 0; s4 < kNnlsMaxMeas / 4; ++s4) {
+            const int k = 4 * s4 + kq;
+            afrag[s4] = (s4 * 4 < kpad && k < nm && va < n_vox) ? Y[(size_t)va * nm + k] : 0.0;
+        }
+        for (int tile = 0; tile < kNnlsMaxBins / 16; ++tile) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < kNnlsMaxMeas / 4; ++s4) {
+                if (s4 * 4 < kpad) {
+                    const double bfrag = bsm[(4 * s4 + kq) * kNnlsMaxBins + tile * 16 + r16];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s4], bfrag, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long vrow = v0 + kq + 4 * r;
+                if (vrow < n_vox) ATY[(size_t)vrow * kNnlsMaxBins + tile * 16 + r16] = acc[r];
+            }
+        }
+    }
+}
+
 // ---- plan-time kernels ------------------------------------------------------------------------
 // G = B^T B + reg^T reg in fp64 (one-off, 2*n^2*(n_meas+n_reg) flop = 35 MFLOP for 250 bins).
 __global__ void gram_kernel(const double *B, const double *RT, int nm, int n, int nreg, double *G) {
@@ -691,6 +749,10 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     P->n_waves = occ * cus;
     P->mglob_stride = kGlobTri;
     PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * kGlobTri * sizeof(double)));
+    if (!getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64) {  // LDS stage of Bp: n_meas * 2 KiB
+        PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_aty_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     PNX_HIPN(hipDeviceSynchronize());
     return PNX_OK;
 }
@@ -701,32 +763,51 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->RT) (void)hipFree(P->RT);
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
+    if (P->aty) (void)hipFree(P->aty);
     if (P->queue) (void)hipFree(P->queue);
     *P = NnlsPlanData();
 }
 
 int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d,
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
-    NnlsArgs a;
-    a.y = y_d;
-    a.coeff = coeff_d;
-    a.rnorm = rnorm_d;
-    a.status = status_d;
-    a.iters = iters_d;
-    a.G = P->G;
-    a.Bp = P->Bp;
-    a.RT = P->RT;
-    a.Mglob = P->Mglob;
-    a.queue = P->queue;
-    a.n_vox = n_vox;
-    a.n_meas = P->n_meas;
-    a.n_bins = P->n_bins;
-    a.n_reg = P->n_reg;
-    a.max_iter = max_iter;
-    PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-    long long grid = n_vox < P->n_waves ? n_vox : P->n_waves;
-    hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
-    PNX_HIPN(hipGetLastError());
+    // Voxels go through in chunks of kAtyChunk: the MFMA Gram step fills ATY for the chunk, the persistent
+    // active-set kernel consumes it (256 voxels per resident wave at full occupancy keep the drain tail small; 2 GiB of ATY scratch).
+    const bool use_mfma = P->aty != nullptr;
+    for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
+        const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
+        NnlsArgs a;
+        a.y = y_d + (size_t)off * P->n_meas;
+        a.coeff = coeff_d + (size_t)off * P->n_bins;
+        a.rnorm = rnorm_d + off;
+        a.status = status_d ? status_d + off : nullptr;
+        a.iters = iters_d ? iters_d + off : nullptr;
+        a.G = P->G;
+        a.Bp = P->Bp;
+        a.RT = P->RT;
+        a.aty = use_mfma ? P->aty : nullptr;
+        a.Mglob = P->Mglob;
+        a.queue = P->queue;
+        a.n_vox = c;
+        a.n_meas = P->n_meas;
+        a.n_bins = P->n_bins;
+        a.n_reg = P->n_reg;
+        a.max_iter = max_iter;
+        if (use_mfma) {
+            const int kpad = (P->n_meas + 3) & ~3;
+            const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);
+            const long long strips = (c + 15) / 16;
+            long long grid = (strips + 3) / 4;
+            const long long cap = (long long)P->cus * 2;
+            if (grid > cap) grid = cap;
+            hipLaunchKernelGGL(nnls_aty_mfma_kernel, dim3((unsigned)grid), dim3(256), lds, stream, a.y, P->Bp, P->aty,
+                               (long long)c, P->n_meas);
+            PNX_HIPN(hipGetLastError());
+        }
+        PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
+        long long grid = c < P->n_waves ? c : P->n_waves;
+        hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+        PNX_HIPN(hipGetLastError());
+    }
     return PNX_OK;
 }
 

@@ -16,6 +16,7 @@ struct NnlsPlanData {
     double *Bp = nullptr;     // (n_meas, 256) zero padded copy (16-byte aligned rows for the kernel)
     double *RT = nullptr;     // (n_bins, n_reg)  row-major: reg transposed (column j of reg contiguous)
     double *G = nullptr;      // (n_bins, n_bins): A^T A = B^T B + reg^T reg, fp64
+    double *aty = nullptr;    // (chunk, 256) A^T y of the current chunk (MFMA Gram step), null = VALU path
     double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
     size_t mglob_stride = 0;  // doubles per wave
     int n_waves = 0;          // persistent waves the scratch was sized for
