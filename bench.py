@@ -181,6 +181,21 @@ def timed(leg, steps, warmup, world, dist, torch):
     return dt, kernel_ms
 
 
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_c_traffic.json;
+    FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is).  bench.py cannot run rocprofv3 around itself,
+    so the figure is the one measured on this kernel and this full-size workload when the profile was taken."""
+    try:
+        with open(os.path.join(HERE, "profiles", "r01_c_traffic.json")) as f:
+            t = json.load(f)
+        for name, v in t.items():
+            if kernel_prefix in name:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def sweep_roofline(device, torch, n_vox_override=0, reps=10):
     """The LM residual/Jacobian/normal-equation sweep as a standalone HBM-streaming kernel (pnx_sweep_f32),
     triexp on the C3 volume: 232 algorithmic bytes per voxel-sweep against the HBM roofline."""
@@ -213,7 +228,9 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=10):
     bytes_per = (n_b + n + ntri + n + 1) * 4
     ach = bytes_per * n_vox / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "sweep_kernel<tri_reduced,f32>", "achieved": ach, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_voxel": bytes_per,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None if n_vox_override else pmc_traffic("sweep_kernel<4, float>"),
+            "algorithmic_bytes_per_launch": bytes_per * n_vox, "algorithmic_bytes_per_voxel": bytes_per,
             "kernel_ms_avg": ms, "voxel_sweeps_per_s": n_vox / (ms * 1e-3), "dtype": "f32"}
 
 
@@ -260,7 +277,9 @@ def main():
                    "pcov": want_pcov if args.workload != "nnls" else None, "parallelism": f"voxel-shard x{world}",
                    "full_size": not args.voxels},
         "roofline": {"bound": "hbm", "kernel": leg.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("curvefit_kernel<4, 5, true, false>") if (args.workload == "triexp" and args.jac == "fd" and not args.voxels) else None,
+                     "algorithmic_bytes_per_launch": leg.bytes_per_voxel * leg.n_vox,
                      "algorithmic_bytes_per_voxel": leg.bytes_per_voxel, "kernel_ms_avg": k_avg * 1e3,
                      "note": "whole-fit kernel is fp64-VALU/transcendental bound, not HBM bound (DESIGN.md section 4)"},
         "check": leg.check(),
