@@ -13,6 +13,8 @@
 // all outputs are parameter-major (k, n_vox), i.e. coalesced across the wavefront axis.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnx_curvefit_kernel.hpp"
 #include "pnx_internal.hpp"
 
@@ -110,19 +112,58 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
     __syncthreads();
     const long long n_tiles = (A.n_vox + kWave - 1) / kWave;
     const long long tiles_per_block = blockDim.x >> 6;
-    for (long long t = (long long)blockIdx.x * tiles_per_block + wave; t < n_tiles; t += (long long)gridDim.x * tiles_per_block) {
+    const long long tstep = (long long)gridDim.x * tiles_per_block;
+    const bool vec_ok = (n_b % VEC) == 0 && (reinterpret_cast<uintptr_t>(A.y) % 16) == 0;
+    constexpr int PF = 8;  // 16-byte chunks per lane held in registers for the NEXT tile (8 KiB per wave)
+    const bool pow2 = (n_b & (n_b - 1)) == 0;
+    const int sh = __ffs(n_b) - 1;  // e / n_b as a shift when n_b is a power of two (no integer division)
+    float4 pre[PF];
+    long long t = (long long)blockIdx.x * tiles_per_block + wave;
+    if (vec_ok && t < n_tiles) {
         const long long v0 = t * kWave;
         const int nv = (A.n_vox - v0) < kWave ? (int)(A.n_vox - v0) : kWave;
-        // ---- coalesced tile load: the tile is one contiguous block of nv * n_b elements
+        const float4 *src4 = reinterpret_cast<const float4 *>(A.y + (size_t)v0 * n_b);
+        const int total4 = nv * n_b / VEC;
+#pragma unroll
+        for (int c = 0; c < PF; ++c)
+            if (lane + kWave * c < total4) pre[c] = src4[lane + kWave * c];
+    }
+    for (; t < n_tiles; t += tstep) {
+        const long long v0 = t * kWave;
+        const int nv = (A.n_vox - v0) < kWave ? (int)(A.n_vox - v0) : kWave;
+        // ---- the tile is one contiguous block of nv * n_b elements: coalesced 16-byte loads (already in flight /
+        // landed in `pre` for the first PF chunks), scattered into the padded LDS rows
         const T *src = A.y + (size_t)v0 * n_b;
         const int total = nv * n_b;
-        if ((n_b % VEC) == 0) {
-            for (int e = lane * VEC; e < total; e += kWave * VEC) {
+        if (vec_ok) {
+#pragma unroll
+            for (int c = 0; c < PF; ++c) {
+                const int e = (lane + kWave * c) * VEC;
+                if (e < total) {
+                    T tmp[VEC];
+                    *reinterpret_cast<float4 *>(tmp) = pre[c];
+                    const int v = pow2 ? (e >> sh) : e / n_b, i = e - v * n_b;
+#pragma unroll
+                    for (int u = 0; u < VEC; ++u) tile[v * stride + i + u] = tmp[u];
+                }
+            }
+            for (int e = (lane + kWave * PF) * VEC; e < total; e += kWave * VEC) {
                 T tmp[VEC];
                 *reinterpret_cast<float4 *>(tmp) = *reinterpret_cast<const float4 *>(src + e);
                 const int v = e / n_b, i = e - v * n_b;
 #pragma unroll
                 for (int u = 0; u < VEC; ++u) tile[v * stride + i + u] = tmp[u];
+            }
+            // next tile's loads fly while this one is computed
+            const long long tn = t + tstep;
+            if (tn < n_tiles) {
+                const long long v0n = tn * kWave;
+                const int nvn = (A.n_vox - v0n) < kWave ? (int)(A.n_vox - v0n) : kWave;
+                const float4 *src4 = reinterpret_cast<const float4 *>(A.y + (size_t)v0n * n_b);
+                const int total4 = nvn * n_b / VEC;
+#pragma unroll
+                for (int c = 0; c < PF; ++c)
+                    if (lane + kWave * c < total4) pre[c] = src4[lane + kWave * c];
             }
         } else {
             for (int e = lane; e < total; e += kWave) {
@@ -171,7 +212,8 @@ static int launch_sweep(const SweepArgs<T> &a, int cus, hipStream_t st) {
     const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (a.n_b + 1));
     const long long n_tiles = (a.n_vox + kWave - 1) / kWave;
     long long want = (n_tiles + 3) / 4;
-    long long cap = (long long)cus * 8;  // memory-bound: ~2048 blocks, grid-stride the rest
+    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 16;
+    long long cap = (long long)cus * bpc;  // memory-bound: ~2048 blocks, grid-stride the rest
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
     static bool attr_set = false;
