@@ -38,8 +38,10 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "curvefit launch: %s", hipGetErrorString(e));
     if (args.pcov) {
         const int pb = 256;
+        ColPerm cp;
+        for (int k = 0; k < kMaxP; ++k) cp.p[k] = (N == Model<MODEL>::NALL && k < 6) ? colperm<MODEL>(k) : k;
         hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
-                           (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b);
+                           (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp);
         e = hipGetLastError();
         if (e != hipSuccess) return set_error(PNX_ERR_HIP, "pcov launch: %s", hipGetErrorString(e));
     }

@@ -154,6 +154,15 @@ template <> struct Model<6> {  // tri full [f1, D1, f2, D2, f3, D3]
     }
 };
 
+// Column order used inside the QR / SVD (speed only, any order gives the same step): columns sorted by typical
+// norm, largest first.  One-sided Jacobi then needs 2.6-3.6 sweeps instead of 3-6 (measured offline on synthetic
+// Jacobians of every model).  Index k of the factor <-> parameter colperm<MODEL>(k).
+template <int MODEL> __host__ __device__ constexpr int colperm(int k) {
+    constexpr int P[7][6] = {{0, 1, 2, 3, 4, 5}, {2, 0, 1, 3, 4, 5}, {2, 0, 1, 3, 4, 5}, {3, 1, 2, 0, 4, 5},
+                             {4, 3, 0, 2, 1, 5}, {4, 3, 0, 2, 1, 5}, {5, 3, 1, 4, 2, 0}};
+    return P[MODEL][k];
+}
+
 template <int MODEL> __device__ constexpr int comp_of_param(int j) {
     for (int c = 0; c < Model<MODEL>::NC; ++c)
         if (Model<MODEL>::dpos(c) == j) return c;
@@ -578,6 +587,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     constexpr int NC = M::NC;
     constexpr bool HASFIXED = (N != NALL);
     static_assert(!(FD && HASFIXED), "finite-difference mode is only built without fixed parameters");
+    // factor column order: static per model when all parameters are free, natural order with fixed parameters
+    auto CP = [](int k) constexpr { return HASFIXED ? k : colperm<MODEL>(k); };
 
     extern __shared__ double smem[];
     const int n_b = A.n_b;
@@ -611,8 +622,19 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         }
     }
 
+#ifdef PNX_CF_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, act[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
+#define CFSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tl; tl = t_; } while (0)
+#define CFACT(k, cond) do { act[k] += __popcll(__ballot(cond)); cnt[k] += 1; } while (0)
+#else
+#define CFSTAMP(k) do {} while (0)
+#define CFACT(k, cond) do {} while (0)
+#endif
     for (;;) {
         // ------------------------------------------------------------------ refill
+        CFSTAMP(7);
+        CFACT(0, state == ST_IDLE);
         while (state == ST_IDLE) {
             const unsigned long long idx = atomicAdd(A.queue, 1ULL);
             if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
@@ -665,6 +687,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             alpha = 0.0;
         }
         if (state == ST_IDLE) break;
+        CFSTAMP(0);
+        CFACT(1, true);
 
         // ------------------------------------------------------------------ row pass at xn
         // residual f = model(xn) - y, cost, Jacobian (closed-form 2-point FD or analytic), g = J^T f, QR of J
@@ -765,9 +789,10 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
                         const double jk = live ? jr[k] : 0.0;
-                        blk[r][k] = jk;
                         gn[k] += jk * rr;
                     }
+#pragma unroll
+                    for (int k = 0; k < N; ++k) blk[r][k] = live ? jr[CP(k)] : 0.0;  // factor column k = parameter CP(k)
                     blk[r][N] = rr;
                 }
                 qr_merge<N, kRowBlk>(Rn, qn, blk);
@@ -775,6 +800,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             cost_new *= 0.5;
         }
 
+        CFSTAMP(1);
         // ------------------------------------------------------------------ phase D: accept / reject
         bool accepted = false;
         int final_status = 0;
@@ -875,6 +901,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             }
         }
 
+        CFSTAMP(2);
+        CFACT(3, state == ST_FINAL);
         // ------------------------------------------------------------------ outputs of finished voxels
         if (state == ST_FINAL) {
             const bool ok = final_status > 0;
@@ -898,6 +926,9 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             state = ST_IDLE;
         }
 
+        CFSTAMP(3);
+        CFACT(4, state == ST_RUN && accepted);
+        CFACT(5, state == ST_RUN);
         if (state == ST_RUN) {
             // -------------------------------------------------------------- heavy phase B (iterate changed)
             if (accepted) {
@@ -916,8 +947,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     q2[i] = qn[i];
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
-                        R2[i][j] = (j >= i) ? Rn[i][j] * d[j] : 0.0;
-                        blk[i][j] = (i == j) ? sqrt(diag_h[i]) : 0.0;
+                        R2[i][j] = (j >= i) ? Rn[i][j] * d[CP(j)] : 0.0;
+                        blk[i][j] = (i == j) ? sqrt(diag_h[CP(i)]) : 0.0;
                     }
                     blk[i][N] = 0.0;
                 }
@@ -956,6 +987,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                 }
                 theta = fmax(0.995, 1 - g_norm);
             }
+            CFSTAMP(4);
             // -------------------------------------------------------------- phase C: trial step
             double V[N][N];
 #pragma unroll
@@ -963,17 +995,34 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #pragma unroll
                 for (int k = 0; k < N; ++k)
                     V[i][k] = PK::kParkV ? vpark[(i * N + k) * kWave] : Vreg[PK::kParkV ? 0 : i][PK::kParkV ? 0 : k];
+            // everything below works in the factor's column order (a relabelling of the parameters)
+            double xP[N], lbP[N], ubP[N], dP[N], ghP[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                xP[i] = x[CP(i)];
+                lbP[i] = lb[CP(i)];
+                ubP[i] = ub[CP(i)];
+                dP[i] = d[CP(i)];
+                ghP[i] = g_h[CP(i)];
+            }
             double p_h[N], p[N], step[N], step_h[N];
             alpha = solve_lsq_trust_region<N>(n_b, uf, s, V, smax, smin, Delta, alpha, p_h);
 #pragma unroll
-            for (int i = 0; i < N; ++i) p[i] = d[i] * p_h[i];
-            predicted = select_step<N>(x, R2, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+            for (int i = 0; i < N; ++i) p[i] = dP[i] * p_h[i];
+            predicted = select_step<N>(xP, R2, ghP, p, p_h, dP, Delta, lbP, ubP, theta, step, step_h);
 #pragma unroll
-            for (int i = 0; i < N; ++i) xn[i] = strictly_feasible0(x[i] + step[i], lb[i], ub[i]);
+            for (int i = 0; i < N; ++i) xn[CP(i)] = strictly_feasible0(xP[i] + step[i], lbP[i], ubP[i]);
             step_h_norm = normn<N>(step_h);
             step_norm = normn<N>(step);
+            CFSTAMP(5);
         }
     }
+#ifdef PNX_CF_STAMP
+    if (threadIdx.x == 0 && blockIdx.x == 3)
+        printf("CFSTAMP refill=%llu pass=%llu D+Blight=%llu final=%llu Bheavy=%llu C=%llu loop=%llu | iters=%llu idle_at_top=%.2f final=%.2f Bheavy=%.2f run=%.2f\n",
+               seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[7], cnt[1], (double)act[0] / cnt[0], (double)act[3] / cnt[3],
+               (double)act[4] / cnt[4], (double)act[5] / cnt[5]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -982,9 +1031,13 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 //   pinv(J^T J) * 2 cost / (m - n)   with singular values <= eps * max(m, n) * s_max dropped
 // (scipy/optimize/_minpack_py.py:1036-1066), NaN for failed voxels (curvefit.py:236-243, 312-317).
 // ---------------------------------------------------------------------------------------------
+struct ColPerm {
+    int p[kMaxP];
+};
+
 template <int N>
 __global__ void __launch_bounds__(256) pcov_kernel(double *pcov, const int8_t *status, const double *cost,
-                                                   long long n_vox, int n_b) {
+                                                   long long n_vox, int n_b, const ColPerm cp) {
     const long long vox = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vox >= n_vox) return;
     double *pc = pcov + (size_t)vox * N * N;
@@ -1036,7 +1089,7 @@ __global__ void __launch_bounds__(256) pcov_kernel(double *pcov, const int8_t *s
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) pc[i * N + j] = (bad || !dof) ? INFINITY : out[i][j] * s_sq;
+        for (int j = 0; j < N; ++j) pc[cp.p[i] * N + cp.p[j]] = (bad || !dof) ? INFINITY : out[i][j] * s_sq;  // factor order -> parameter order
 }
 
 }  // namespace pnx
