@@ -30,6 +30,7 @@ constexpr int kMaxP = 8;
 constexpr int kRowBlk = 8;          // rows merged into the QR factor per Householder block step
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kSqrtEps = 1.4901161193847656e-08;
+typedef __attribute__((address_space(3))) void lds_void;
 
 struct CurvefitArgs {
     const double *y;      // (n_vox, n_b)
@@ -565,7 +566,8 @@ template <int N> struct Park {
     static constexpr bool kParkV = (N <= 5);            // right singular vectors live in LDS between B and C
     static constexpr int NV = kParkV ? N * N : 0;
     // doubles of LDS per wave besides the b-value table
-    __host__ __device__ static constexpr int per_wave(int n_b) { return kWave * (n_b + NR + NV); }
+    // the signal tile is [ceil(n_b / 2)][64 lanes][2] (the layout a 16-byte LDS-DMA load per lane produces)
+    __host__ __device__ static constexpr int per_wave(int n_b) { return kWave * (((n_b + 1) & ~1) + NR + NV); }
 };
 
 // Loop order -- one iteration = one row pass per lane:
@@ -595,11 +597,14 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     double *bsh = smem;                                   // [kMaxB]
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    double *ysh = smem + kMaxB + (size_t)wave * PK::per_wave(n_b) + lane;  // [n_b][64]
-    double *rpark = ysh + (size_t)n_b * kWave;                                // [NR][64]
+    double *ytile = smem + kMaxB + (size_t)wave * PK::per_wave(n_b);       // [ceil(n_b/2)][64][2], wave-uniform base
+    double *ysh = ytile + 2 * lane;                                         // this lane's pair column
+    double *rpark = ytile + (size_t)((n_b + 1) & ~1) * kWave + lane;        // [NR][64]
     double *vpark = rpark + (size_t)PK::NR * kWave;                           // [NV][64]
     for (int i = threadIdx.x; i < n_b; i += blockDim.x) bsh[i] = A.b[i];
     __syncthreads();
+    // signal rows are 16-byte aligned pairs => the refill can use asynchronous global->LDS loads
+    const bool dma_ok = ((n_b & 1) == 0) && ((reinterpret_cast<uintptr_t>(A.y) & 15) == 0);
 
     // ---- per-lane persistent state
     int state = ST_IDLE;
@@ -631,69 +636,74 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #define CFSTAMP(k) do {} while (0)
 #define CFACT(k, cond) do {} while (0)
 #endif
-    for (;;) {
-        // ------------------------------------------------------------------ refill
-        CFSTAMP(7);
-        CFACT(0, state == ST_IDLE);
-        while (state == ST_IDLE) {
-            const unsigned long long idx = atomicAdd(A.queue, 1ULL);
-            if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
-            vox = (long long)idx;
-            bool finite = true;
-            const double *yv = A.y + (size_t)vox * n_b;
-            for (int i = 0; i < n_b; ++i) {
-                const double yy = yv[i];
-                finite = finite && isfinite(yy);
-                ysh[i * kWave] = yy;
-            }
-            bool okb = true, okp = true;
-            double p0v[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                if (PV) {
-                    p0v[k] = A.p0[(size_t)k * A.n_vox + vox];
-                    lb[k] = A.lo[(size_t)k * A.n_vox + vox];
-                    ub[k] = A.hi[(size_t)k * A.n_vox + vox];
-                } else
-                    p0v[k] = A.p0s[k];
-                okb = okb && (lb[k] < ub[k]);                          // least_squares.py:814-816
-                okp = okp && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);  // least_squares.py:818-819
-            }
-            if (HASFIXED) {
-#pragma unroll
-                for (int j = 0; j < NALL; ++j) pfull[j] = 0;
-                for (int f = 0; f < A.n_fixed; ++f) {
-                    const double fv = A.fixed_per_voxel ? A.fixed[(size_t)f * A.n_vox + vox] : A.fixeds[f];
-#pragma unroll
-                    for (int j = 0; j < NALL; ++j)
-                        if (A.fixed_idx[f] == j) pfull[j] = fv;
-                }
-            }
-            if (!finite || !okb || !okp) {
-                // reference: ValueError inside curve_fit -> params = p0, cov = NaN, success = False
-                const int st = !finite ? -2 : (!okb ? -1 : -3);
-#pragma unroll
-                for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = p0v[k];
-                if (A.status) A.status[vox] = (int8_t)st;  // pcov_kernel writes the NaN covariance
-                if (A.nfev) A.nfev[vox] = 0;
-                if (A.cost) A.cost[vox] = NAN;
-                continue;  // stays IDLE -> next voxel
-            }
-#pragma unroll
-            for (int k = 0; k < N; ++k) xn[k] = strictly_feasible_r(p0v[k], lb[k], ub[k]);
-            state = ST_INIT;
-            nfev = 0;
-            term = -99;
-            alpha = 0.0;
+    auto refill = [&]() {
+    while (state == ST_IDLE) {
+        const unsigned long long idx = atomicAdd(A.queue, 1ULL);
+        if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
+        vox = (long long)idx;
+        const double *yv = A.y + (size_t)vox * n_b;
+        if (dma_ok) {
+            // asynchronous refill: 16-byte global->LDS loads (no VGPR round trip, nothing waits here); they land
+            // while the other lanes run phases B / C and are waited for (vmcnt) right before the next row pass
+            for (int c = 0; c < n_b / 2; ++c)
+                __builtin_amdgcn_global_load_lds((const void *)(yv + 2 * c), (lds_void *)(ytile + c * 2 * kWave), 16, 0, 0);
+        } else {
+            for (int i = 0; i < n_b; ++i) ysh[(i >> 1) * 2 * kWave + (i & 1)] = yv[i];
         }
+        bool okb = true, okp = true;
+        double p0v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (PV) {
+                p0v[k] = A.p0[(size_t)k * A.n_vox + vox];
+                lb[k] = A.lo[(size_t)k * A.n_vox + vox];
+                ub[k] = A.hi[(size_t)k * A.n_vox + vox];
+            } else
+                p0v[k] = A.p0s[k];
+            okb = okb && (lb[k] < ub[k]);                          // least_squares.py:814-816
+            okp = okp && (p0v[k] >= lb[k]) && (p0v[k] <= ub[k]);  // least_squares.py:818-819
+        }
+        if (HASFIXED) {
+#pragma unroll
+            for (int j = 0; j < NALL; ++j) pfull[j] = 0;
+            for (int f = 0; f < A.n_fixed; ++f) {
+                const double fv = A.fixed_per_voxel ? A.fixed[(size_t)f * A.n_vox + vox] : A.fixeds[f];
+#pragma unroll
+                for (int j = 0; j < NALL; ++j)
+                    if (A.fixed_idx[f] == j) pfull[j] = fv;
+            }
+        }
+        if (!okb || !okp) {
+            // reference: ValueError inside curve_fit -> params = p0, cov = NaN, success = False
+            // (a non-finite signal is detected in the voxel's first row pass)
+            const int st = !okb ? -1 : -3;
+#pragma unroll
+            for (int k = 0; k < N; ++k) A.popt[(size_t)k * A.n_vox + vox] = p0v[k];
+            if (A.status) A.status[vox] = (int8_t)st;  // pcov_kernel writes the NaN covariance
+            if (A.nfev) A.nfev[vox] = 0;
+            if (A.cost) A.cost[vox] = NAN;
+            continue;  // stays IDLE -> next voxel
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) xn[k] = strictly_feasible_r(p0v[k], lb[k], ub[k]);
+        state = ST_INIT;
+        nfev = 0;
+        term = -99;
+        alpha = 0.0;
+    }
+    };
+    refill();
+    for (;;) {
+        CFSTAMP(7);
         if (state == ST_IDLE) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA signal tiles have landed
         CFSTAMP(0);
         CFACT(1, true);
 
         // ------------------------------------------------------------------ row pass at xn
         // residual f = model(xn) - y, cost, Jacobian (closed-form 2-point FD or analytic), g = J^T f, QR of J
         double Rn[N][N], qn[N], gn[N], cost_new = 0;
-        bool finite_f = true;
+        bool finite_f = true, yfinite = true;
         {
             double pe[NALL];  // full parameter vector at the evaluation point
             if (HASFIXED) {
@@ -740,7 +750,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     const int ii = live ? i : 0;
                     const double bb = bsh[ii];
                     const double nb = -bb;
-                    const double yi = ysh[ii * kWave];
+                    const double yi = ysh[(ii >> 1) * 2 * kWave + (ii & 1)];
+                    yfinite = yfinite && isfinite(yi);
                     double E[NC];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
@@ -806,8 +817,9 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         int final_status = 0;
         if (state == ST_INIT) {
             if (!finite_f) {
-                // least_squares.py:857-858 "Residuals are not finite in the initial point" -> failure sentinel
-                final_status = -4;
+                // non-finite signal: curve_fit's asarray_chkfinite raises (-2); otherwise least_squares.py:857-858
+                // "Residuals are not finite in the initial point" (-4) -> failure sentinel either way
+                final_status = yfinite ? -4 : -2;
                 cost = NAN;
                 nfev = 0;
                 state = ST_FINAL;
@@ -925,6 +937,8 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
             }
             state = ST_IDLE;
         }
+        CFACT(0, state == ST_IDLE);
+        if (state == ST_IDLE) refill();  // claim the next voxel now: its signal streams in behind phases B / C
 
         CFSTAMP(3);
         CFACT(4, state == ST_RUN && accepted);
