@@ -176,15 +176,16 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
         ob[s] = 0;
     }
     const int p_lds = p < kLdsRows ? p : kLdsRows;
+    // branch-free body (clamped address, masked product) so that the unrolled steps keep their LDS reads in flight
 #pragma unroll 8
     for (int i = 0; i < p_lds; ++i) {
         const double a = rl(va[0], i);
         const double b = TWO ? rl(vb[0], i) : 0.0;
-        if (lane <= i) {
-            const double m = Mlds[tri(i) + lane];
-            oa[0] += a * m;
-            if (TWO) ob[0] += b * m;
-        }
+        const bool on = lane <= i;
+        const double m0 = Mlds[tri(i) + (on ? lane : 0)];
+        const double m = on ? m0 : 0.0;
+        oa[0] += a * m;
+        if (TWO) ob[0] += b * m;
     }
     for_pos<4>(kLdsRows, p, [&](int i, auto S) {
         constexpr int si = decltype(S)::value;
@@ -194,11 +195,11 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #pragma unroll
         for (int s = 0; s <= si; ++s) {
             const int k = lane + kW * s;
-            if (k <= i) {
-                const double m = row[k];
-                oa[s] += a * m;
-                if (TWO) ob[s] += b * m;
-            }
+            const bool on = k <= i;
+            const double m0 = row[on ? k : 0];
+            const double m = on ? m0 : 0.0;
+            oa[s] += a * m;
+            if (TWO) ob[s] += b * m;
         }
     });
 }
@@ -340,11 +341,13 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
                 {
                     // LDS rows as a column sweep: uniform k, lane i accumulates M[i][k] g_k for i >= k
                     const int plim = p < kLdsRows ? p : kLdsRows;
-                    const double *row0 = Mlds + tri(lane < plim ? lane : 0);
+                    const bool mine = lane < plim;
+                    const double *row0 = Mlds + tri(mine ? lane : 0);
 #pragma unroll 8
                     for (int k = 0; k < plim; ++k) {
                         const double gk = rl(g[0], k);
-                        if (lane >= k && lane < plim) l[0] += row0[k] * gk;
+                        const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
+                        l[0] += (mine && lane >= k) ? m0 * gk : 0.0;
                     }
                 }
                 // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
@@ -355,7 +358,9 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
 #pragma unroll
                     for (int s = 0; s <= si; ++s) {
                         const int k = lane + kW * s;
-                        if (k <= i) part += row[k] * g[s];
+                        const bool on = k <= i;
+                        const double m0 = row[on ? k : 0];
+                        part += on ? m0 * g[s] : 0.0;
                     }
                     const double li = wave_sum(part);
                     if (lane == (i & 63)) l[si] = li;
