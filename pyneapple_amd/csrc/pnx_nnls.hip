@@ -403,8 +403,11 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
 
             // ---- column jmax enters: new row of M and z = M^T q in one sweep over M
             {
+                // one sweep over M gives the new row r = -(l^T M) / lam.  z = M^T q is then a rank-one update of the
+                // current solution (x == z = M_old^T q_old whenever a column enters): z_k = x_k + r_k * qn.  After
+                // every removal z is recomputed from scratch (second sweep below), so nothing drifts.
                 double a1[kSlots], a2[kSlots];
-                col_pass<true>(Mlds, Mg, p, lane, l, q, a1, a2);
+                col_pass<false>(Mlds, Mg, p, lane, l, l, a1, a2);
                 const double inv = 1.0 / lam;
                 double *rowp = (p < kLdsRows) ? (Mlds + tri(p)) : (Mg + (tri(p) - kLdsTri));
 #pragma unroll
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
                     if (k < p) {
                         const double r = -a1[s] * inv;
                         rowp[k] = r;
-                        z[s] = a2[s] + r * qn;
+                        z[s] = x[s] + r * qn;
                     } else if (k == p) {
                         rowp[k] = inv;
                         z[s] = qn * inv;
