@@ -1,0 +1,175 @@
+"""IDEAL multi-resolution driver on top of the batched HIP solver (BASELINE config 5).
+
+Mirrors `pyneapple.fitters.IDEALFitter.fit` (reference src/pyneapple/fitters/ideal.py:95-259): for every row of
+`dim_steps` the image, the segmentation and the previous level's parameter maps are resized to the level's
+grid, p0 is clipped to the solver's global bounds, per-voxel bounds `p0 * (1 -/+ tol)` are derived, the mask
+is thresholded (all-voxel fallback when it vanishes) and ONE batched `solver.fit` call with per-voxel
+`(n_params, n_pixels)` p0 / bounds arrays runs the whole level on the GPU.
+
+The reference resizes with `cv2.resize` per slice and channel (ideal.py:299-320); OpenCV is not a dependency here:
+`resize2d` restates its INTER_LINEAR / INTER_CUBIC arithmetic (half-pixel centres, cubic a = -0.75, replicated
+border, no anti-aliasing) as two small dense weight matrices applied to all slices and channels at once.
+cv2 is absent from the build container, so this restatement is pinned by analytic cases only
+(tests/test_ideal.py) -- "parity unpinned" against OpenCV itself.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+_INTERPOLATION_METHODS = ("linear", "cubic")
+
+
+def _cubic_coeffs(x: np.ndarray) -> np.ndarray:
+    """OpenCV interpolateCubic, A = -0.75: weights of the taps at offsets -1, 0, +1, +2."""
+    A = -0.75
+    c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A
+    c1 = ((A + 2) * x - (A + 3)) * x * x + 1
+    c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1
+    return np.stack([c0, c1, c2, 1.0 - c0 - c1 - c2], axis=-1)
+
+
+def resize_weights(n_src: int, n_dst: int, method: str) -> np.ndarray:
+    """(n_dst, n_src) matrix W with out = W @ in along one axis, OpenCV `resize` semantics."""
+    if method not in _INTERPOLATION_METHODS:
+        raise ValueError(f"Invalid interpolation method: {method}. Must be one of {_INTERPOLATION_METHODS}.")
+    W = np.zeros((n_dst, n_src))
+    scale = n_src / n_dst
+    f = (np.arange(n_dst) + 0.5) * scale - 0.5
+    s = np.floor(f).astype(int)
+    fr = f - s
+    rows = np.arange(n_dst)
+    if method == "linear":
+        lo = s < 0
+        fr = np.where(lo, 0.0, fr)
+        s = np.where(lo, 0, s)
+        hi = s >= n_src - 1
+        fr = np.where(hi, 0.0, fr)
+        s = np.where(hi, n_src - 1, s)
+        np.add.at(W, (rows, s), 1.0 - fr)
+        np.add.at(W, (rows, np.minimum(s + 1, n_src - 1)), fr)
+    else:
+        c = _cubic_coeffs(fr)
+        for k in range(4):
+            np.add.at(W, (rows, np.clip(s - 1 + k, 0, n_src - 1)), c[:, k])  # replicated border
+    return W
+
+
+def resize2d(array: np.ndarray, target_shape, method: str = "cubic") -> np.ndarray:
+    """Resize the first two axes of `array` (X, Y, ...) to `target_shape[:2]` (reference `_interpolate_array`)."""
+    tx, ty = int(target_shape[0]), int(target_shape[1])
+    if array.dtype.kind != "f":
+        array = array.astype(np.float32)  # ideal.py:309-310
+    Wx = resize_weights(array.shape[0], tx, method).astype(array.dtype)
+    Wy = resize_weights(array.shape[1], ty, method).astype(array.dtype)
+    out = np.tensordot(Wx, array, axes=(1, 0))            # (tx, Y, ...)
+    out = np.tensordot(Wy, out, axes=(1, 1))              # (ty, tx, ...)
+    return np.ascontiguousarray(np.swapaxes(out, 0, 1))   # (tx, ty, ...)
+
+
+class HipIDEALFitter:
+    """IDEAL pyramid around a `HipCurveFitSolver` (any solver with the CurveFitSolver interface works).
+
+    Args follow IDEALFitter.__init__ (ideal.py:46-92): solver, dim_steps (n_steps, ideal_dims), step_tol
+    {param: fraction}, ideal_dims, segmentation_threshold, interpolation_method ("linear" | "cubic").
+    After `fit`: `step_params` (one (X, Y, Z, n_params) map per level), `fitted_params_`, `pixel_indices`,
+    `fit_time`.
+    """
+
+    def __init__(self, solver, dim_steps, step_tol: dict, ideal_dims: int = 2, segmentation_threshold: float = 0.2,
+                 interpolation_method: str = "cubic", **fitter_kwargs):
+        if interpolation_method not in _INTERPOLATION_METHODS:
+            raise ValueError(
+                f"Invalid interpolation method: {interpolation_method}. Must be one of {_INTERPOLATION_METHODS}.")
+        self.solver = solver
+        self.dim_steps = np.asarray(dim_steps)
+        self.step_tol = step_tol
+        self.ideal_dims = ideal_dims
+        self.segmentation_threshold = segmentation_threshold
+        self.interpolation_method = interpolation_method
+        self.step_params: list[np.ndarray] = []
+        self.fitted_params_: dict = {}
+        self.pixel_indices = None
+        self.fit_time = None
+
+    # ideal.py:261-297 --------------------------------------------------------------------------
+    def _validate(self, xdata, image):
+        if np.ndim(xdata) != 1:
+            raise ValueError(f"xdata must be a 1D array, but got shape {np.shape(xdata)}.")
+        if image.shape[-1] != len(xdata):
+            raise ValueError(f"ydata second dimension {image.shape[-1]} does not match xdata length {len(xdata)}.")
+        if not isinstance(self.step_tol, dict):
+            raise ValueError("step_tol must be a dict mapping parameter names to tolerance fractions, "
+                             f"e.g. {{'S0': 0.5, 'D': 0.2}}. Got {type(self.step_tol).__name__}.")
+        names = self.solver.model.param_names
+        if set(names) - set(self.step_tol):
+            raise ValueError(f"step_tol keys {set(self.step_tol)} do not match model parameter names {names}")
+        ds = self.dim_steps
+        if ds.ndim != 2:
+            raise ValueError("dim_steps must be a 2D array of shape (n_steps, ideal_dims).")
+        if ds.shape[1] != self.ideal_dims:
+            raise ValueError(f"dim_steps must have {self.ideal_dims} columns corresponding to ideal_dims.")
+        for i in range(ds.shape[0] - 1):
+            if not np.all(ds[i + 1] > ds[i]):
+                raise ValueError(f"dim_steps row {i + 1} must be greater than row {i} (monotonic increase).")
+        if image.ndim == 3:
+            if self.ideal_dims == 3:
+                raise ValueError(f"Image dimension ({image.ndim}) not sufficient for 3D interpolation "
+                                 f"(ideal_dims={self.ideal_dims})")
+            image = np.expand_dims(image, axis=-2)
+        elif image.ndim != 4:
+            raise ValueError(f"Image Array needs to be 3 or 4 not {image.ndim}")
+        if not np.allclose(ds[-1], image.shape[: self.ideal_dims]):
+            raise ValueError("The last step in dim_steps must match the spatial dimensions of the image.")
+        return image
+
+    def fit(self, xdata, image, segmentation=None, **fit_kwargs):
+        xdata = np.asarray(xdata, float)
+        image = self._validate(xdata, np.asarray(image))
+        t0 = time.perf_counter()
+        if self.ideal_dims == 2 and image.ndim == 4:
+            dim_steps = np.hstack([self.dim_steps, np.full((self.dim_steps.shape[0], 1), image.shape[2])])
+        else:
+            dim_steps = self.dim_steps
+        if segmentation is None:
+            segmentation = np.ones(image.shape[:3], dtype=int)
+        segmentation = np.asarray(segmentation)
+        if segmentation.shape != image.shape[:3]:
+            raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {image.shape[:3]}.")
+        seg4 = segmentation[..., np.newaxis]
+        names = list(self.solver.model.param_names)
+        n_params = len(names)
+        p0_vals = np.array([self.solver.p0[n] for n in names], float)
+        lo_vals = np.array([self.solver.bounds[n][0] for n in names], float)
+        hi_vals = np.array([self.solver.bounds[n][1] for n in names], float)
+        tol_vals = np.array([self.step_tol[n] for n in names], float)
+        self.step_params = []
+        method = self.interpolation_method
+        for step_index, step in enumerate(dim_steps):
+            shape = tuple(int(s) for s in step)
+            if step_index == 0:
+                p0 = np.broadcast_to(p0_vals, (*shape, n_params)).copy()
+                lower = np.broadcast_to(lo_vals, (*shape, n_params)).copy()
+                upper = np.broadcast_to(hi_vals, (*shape, n_params)).copy()
+            else:
+                p0 = np.clip(resize2d(self.step_params[-1], shape, method), lo_vals, hi_vals)
+                lower = np.clip(p0 * (1 - tol_vals), lo_vals, hi_vals)
+                upper = np.clip(p0 * (1 + tol_vals), lo_vals, hi_vals)
+            img = resize2d(image, shape, method)
+            mask = resize2d(seg4, shape, method)[..., 0] > self.segmentation_threshold
+            if not mask.any():  # ideal.py:199-209: ROI too sparse at this level -> fit everything
+                mask = np.ones(shape, dtype=bool)
+            pixels = np.ascontiguousarray(img[mask], dtype=np.float64)       # (n_px, N), C order of np.where
+            idx = np.nonzero(mask)
+            self.solver.fit(xdata, pixels, p0=np.ascontiguousarray(p0[mask].T),
+                            bounds=(np.ascontiguousarray(lower[mask].T), np.ascontiguousarray(upper[mask].T)),
+                            **fit_kwargs)
+            param_map = np.zeros((*shape, n_params))
+            for k, n in enumerate(names):
+                param_map[idx[0], idx[1], idx[2], k] = np.atleast_1d(self.solver.params_[n])
+            self.step_params.append(param_map)
+        self.pixel_indices = list(zip(*idx))
+        self.fitted_params_ = dict(self.solver.params_)
+        self.fit_time = time.perf_counter() - t0
+        return self

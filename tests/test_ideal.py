@@ -1,0 +1,132 @@
+"""IDEAL driver: OpenCV-semantics resize pinned by analytic cases (cv2 itself is absent here, so the
+restatement is 'parity unpinned' against OpenCV), validation mirrored from the reference's tests/test_fitter_ideal.py,
+and an end-to-end 3-level pyramid on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from pyneapple_amd.ideal import HipIDEALFitter, resize2d, resize_weights
+from pyneapple_amd.models import BiExpModel
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+@pytest.mark.parametrize("n_src,n_dst", [(4, 8), (8, 4), (5, 13), (16, 16), (2, 64), (64, 3)])
+def test_resize_weights_partition_of_unity(method, n_src, n_dst):
+    W = resize_weights(n_src, n_dst, method)
+    assert W.shape == (n_dst, n_src)
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=1e-14)  # constants are reproduced exactly
+    if n_src == n_dst:
+        np.testing.assert_allclose(W, np.eye(n_src), atol=1e-14)  # same size = identity
+
+
+def test_linear_kernel_reproduces_affine_functions():
+    """Bilinear at half-pixel centres is exact for affine functions away from the replicated border."""
+    n_src, n_dst = 16, 40
+    src = 3.0 + 0.5 * np.arange(n_src)
+    out = resize_weights(n_src, n_dst, "linear") @ src
+    x = (np.arange(n_dst) + 0.5) * n_src / n_dst - 0.5  # source coordinate of every output sample
+    inner = (x > 0) & (x < n_src - 1)
+    np.testing.assert_allclose(out[inner], 3.0 + 0.5 * x[inner], atol=1e-12)
+    assert out.min() >= src.min() - 1e-12 and out.max() <= src.max() + 1e-12
+
+
+def test_cubic_kernel_is_opencvs():
+    """OpenCV's bicubic uses a = -0.75 (not Catmull-Rom's -0.5): known tap weights, symmetric, interpolating."""
+    from pyneapple_amd.ideal import _cubic_coeffs
+
+    np.testing.assert_allclose(_cubic_coeffs(np.array([0.5]))[0], [-0.09375, 0.59375, 0.59375, -0.09375], atol=1e-15)
+    np.testing.assert_allclose(_cubic_coeffs(np.array([0.0]))[0], [0, 1, 0, 0], atol=1e-15)
+    np.testing.assert_allclose(_cubic_coeffs(np.array([0.25]))[0], _cubic_coeffs(np.array([0.75]))[0][::-1], atol=1e-15)
+    # upscaling by 2: output samples sit at +-0.25 of a source pixel; taps come from the replicated border at the edge
+    W = resize_weights(4, 8, "cubic")
+    c = _cubic_coeffs(np.array([0.75]))[0]
+    np.testing.assert_allclose(W[0], [c[0] + c[1] + c[2], c[3], 0, 0], atol=1e-15)  # f = -0.25: taps -2,-1,0 clamp to 0
+    np.testing.assert_allclose(W[3], np.r_[_cubic_coeffs(np.array([0.25]))[0]], atol=1e-15)  # f = 1.25: taps 0..3
+
+
+def test_linear_downscale_by_two_is_block_mean():
+    img = np.arange(64.0).reshape(8, 8)
+    out = resize2d(img[..., None, None], (4, 4), "linear")[..., 0, 0]
+    np.testing.assert_allclose(out, img.reshape(4, 2, 4, 2).mean(axis=(1, 3)))
+
+
+def test_resize2d_shapes_and_dtypes():
+    a = np.random.default_rng(0).uniform(size=(8, 6, 3, 5))
+    out = resize2d(a, (16, 12, 3), "cubic")
+    assert out.shape == (16, 12, 3, 5) and out.dtype == a.dtype
+    seg = np.ones((8, 6, 3, 1), dtype=np.int64)
+    s = resize2d(seg, (4, 3, 3), "linear")
+    assert s.dtype == np.float32 and np.allclose(s, 1.0)  # integer masks are cast to float32 (ideal.py:309-310)
+    with pytest.raises(ValueError):
+        resize2d(a, (4, 4), "nearest")
+
+
+class _FakeSolver:
+    """Records the per-voxel arrays each level receives (the reference's test_fitter_ideal.py uses mocks too)."""
+
+    def __init__(self):
+        self.model = BiExpModel()
+        self.p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001}
+        self.bounds = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}
+        self.calls = []
+        self.params_ = {}
+
+    def fit(self, xdata, ydata, p0=None, bounds=None, **kw):
+        self.calls.append((ydata.shape, p0.copy(), bounds[0].copy(), bounds[1].copy()))
+        self.params_ = {n: p0[k] * 1.1 for k, n in enumerate(self.model.param_names)}
+        return self
+
+
+def test_levels_shapes_bounds_and_fallback():
+    b = np.linspace(0, 1000, 8)
+    image = np.ones((16, 16, 2, 8))
+    seg = np.zeros((16, 16, 2), dtype=int)
+    seg[0, 0, :] = 1  # vanishes at the coarse levels -> all-voxel fallback there
+    s = _FakeSolver()
+    f = HipIDEALFitter(s, np.array([[2, 2], [4, 4], [16, 16]]), {"f1": 0.2, "D1": 0.3, "D2": 0.4})
+    f.fit(b, image, segmentation=seg)
+    assert [c[0] for c in s.calls] == [(2 * 2 * 2, 8), (4 * 4 * 2, 8), (2, 8)]
+    assert [p.shape for p in f.step_params] == [(2, 2, 2, 3), (4, 4, 2, 3), (16, 16, 2, 3)]
+    p0, lo, hi = s.calls[1][1:]
+    assert p0.shape == (3, 32) and np.allclose(p0[0], 0.22)            # level-0 result, resized, clipped
+    np.testing.assert_allclose(lo[1], np.clip(p0[1] * 0.7, 1e-3, 0.1))  # p0 * (1 - tol) clipped to global bounds
+    np.testing.assert_allclose(hi[2], np.clip(p0[2] * 1.4, 1e-5, 5e-3))
+    assert len(f.pixel_indices) == 2 and set(f.fitted_params_) == {"f1", "D1", "D2"}
+
+
+def test_validation_errors():
+    s = _FakeSolver()
+    b = np.linspace(0, 1000, 8)
+    img = np.ones((8, 8, 1, 8))
+    with pytest.raises(ValueError):
+        HipIDEALFitter(s, np.array([[2, 2], [8, 8]]), {"f1": 0.2}).fit(b, img)              # step_tol keys
+    with pytest.raises(ValueError):
+        HipIDEALFitter(s, np.array([[4, 4], [2, 2], [8, 8]]), {"f1": .2, "D1": .2, "D2": .2}).fit(b, img)  # monotonic
+    with pytest.raises(ValueError):
+        HipIDEALFitter(s, np.array([[2, 2], [4, 4]]), {"f1": .2, "D1": .2, "D2": .2}).fit(b, img)  # last != image
+    with pytest.raises(ValueError):
+        HipIDEALFitter(s, np.array([[8, 8]]), {"f1": .2, "D1": .2, "D2": .2}, interpolation_method="area")
+
+
+@pytest.mark.gpu
+def test_three_level_pyramid_on_gpu(gpu):
+    from pyneapple_amd.solvers import HipCurveFitSolver
+
+    rng = np.random.default_rng(0)
+    b = np.linspace(0, 1200, 24)
+    X = Y = 32
+    f1 = 0.2 + 0.1 * np.sin(np.linspace(0, 3, X))[:, None] * np.ones((1, Y))
+    D1 = np.full((X, Y), 0.02)
+    D2 = 0.001 + 0.0005 * np.linspace(0, 1, Y)[None, :] * np.ones((X, 1))
+    img = (f1[..., None] * np.exp(-b * D1[..., None]) + (1 - f1[..., None]) * np.exp(-b * D2[..., None]))[:, :, None, :]
+    img = img * (1 + 0.005 * rng.standard_normal(img.shape))
+    solver = HipCurveFitSolver(model=BiExpModel(), max_iter=250, tol=1e-8, p0={"f1": 0.2, "D1": 0.01, "D2": 0.001},
+                               bounds={"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)})
+    f = HipIDEALFitter(solver, np.array([[4, 4], [16, 16], [32, 32]]), {"f1": 0.5, "D1": 0.5, "D2": 0.5})
+    f.fit(b, img)
+    assert [p.shape for p in f.step_params] == [(4, 4, 1, 3), (16, 16, 1, 3), (32, 32, 1, 3)]
+    final = f.step_params[-1][:, :, 0, :]
+    assert np.median(np.abs(final[..., 0] - f1) / f1) < 0.05
+    assert np.median(np.abs(final[..., 2] - D2) / D2) < 0.05
+    assert (np.asarray(solver.diagnostics_["status"]) > 0).mean() > 0.95
