@@ -87,6 +87,12 @@ typedef struct pnx_curvefit_opts {
     int32_t fixed_per_voxel;             /* 0: fixed is (n_fixed,); 1: (n_fixed, n_vox)  (curvefit.py:161-169) */
     int32_t max_nfev;                    /* reference's max_iter -> SciPy max_nfev (curvefit.py:303) */
     int32_t jac_mode;                    /* pnx_jac_mode */
+    int32_t t1_mode;                     /* 0 none; 1 T1: S*(1-exp(-TR/T1)); 2 STEAM: additionally *exp(-TM/T1).
+                                            T1 is then one more model parameter, appended last
+                                            (model_functions/multiexp.py:210-241, models/*.py `names.append("T1")`) */
+    int32_t reserved0;
+    double tr;                           /* repetition time, same unit as T1 */
+    double tm;                           /* mixing time (STEAM) */
     double ftol;                         /* reference's tol (curvefit.py:304) */
     double xtol;                         /* SciPy default 1e-8 */
     double gtol;                         /* SciPy default 1e-8 */
@@ -97,7 +103,7 @@ int pnx_version(void);
 int pnx_device_count(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
 int pnx_last_error(char *buf, int n);
-/* Number of parameters of a model, or PNX_ERR_INVALID. */
+/* Number of parameters of a model without the optional T1 parameter, or PNX_ERR_INVALID. */
 int pnx_model_n_params(int model);
 
 /*

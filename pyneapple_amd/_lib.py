@@ -38,7 +38,8 @@ class CurvefitOpts(C.Structure):
         ("model", C.c_int32), ("n_b", C.c_int32), ("n_free", C.c_int32), ("n_fixed", C.c_int32),
         ("free_idx", C.c_int32 * PNX_MAX_PARAMS), ("fixed_idx", C.c_int32 * PNX_MAX_PARAMS),
         ("per_voxel_p0_bounds", C.c_int32), ("fixed_per_voxel", C.c_int32), ("max_nfev", C.c_int32),
-        ("jac_mode", C.c_int32), ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
+        ("jac_mode", C.c_int32), ("t1_mode", C.c_int32), ("reserved0", C.c_int32), ("tr", C.c_double),
+        ("tm", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
     ]
 
 

@@ -25,8 +25,8 @@ def _is_torch(a):
 
 
 def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, max_nfev=250, ftol=1e-8, xtol=1e-8,
-              gtol=1e-8, jac="fd"):
-    n_all = len(MODEL_PARAM_NAMES[model])
+              gtol=1e-8, jac="fd", t1_mode=0, tr=0.0, tm=0.0):
+    n_all = len(MODEL_PARAM_NAMES[model]) + (1 if t1_mode else 0)
     fixed_idx = [int(i) for i in fixed_idx]
     free_idx = [i for i in range(n_all) if i not in fixed_idx]
     o = CurvefitOpts()
@@ -42,12 +42,13 @@ def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, 
     o.fixed_per_voxel = int(fixed_per_voxel)
     o.max_nfev = int(max_nfev)
     o.jac_mode = JAC_FD if jac == "fd" else JAC_ANALYTIC
+    o.t1_mode, o.tr, o.tm = int(t1_mode), float(tr), float(tm)
     o.ftol, o.xtol, o.gtol = float(ftol), float(xtol), float(gtol)
     return o
 
 
 def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev=250, ftol=1e-8, xtol=1e-8,
-             gtol=1e-8, jac="fd", want_pcov=True, device=0):
+             gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0):
     """Batched bounded NLLS on host (numpy) arrays.  Shapes as in include/pnx.h.
 
     Returns dict(popt (n_free, n_vox), pcov (n_vox, n_free, n_free) | None, status int8, nfev int32, cost).
@@ -67,7 +68,7 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
     if len(fixed_idx):
         fv = np.ascontiguousarray(fixed_vals, np.float64)
         fpv = fv.ndim == 2
-    o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac)
+    o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac, t1_mode, tr, tm)
     n = o.n_free
     want = (n, n_vox) if per_voxel else (n,)
     if p0.shape != want or lo.shape != want or hi.shape != want:

@@ -115,6 +115,9 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     a.fixed_per_voxel = o->fixed_per_voxel;
     a.max_nfev = o->max_nfev > 0 ? o->max_nfev : 100 * o->n_free;  // least_squares: max_nfev=None -> 100*n
     a.n_fixed = o->n_fixed;
+    a.t1_mode = o->t1_mode;
+    a.tr = o->tr;
+    a.tm = o->tm;
     a.ftol = o->ftol;
     a.xtol = o->xtol;
     a.gtol = o->gtol;
@@ -145,8 +148,10 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
 
 static int check_curvefit_opts(const pnx_curvefit_opts *o) {
     if (!o) return set_error(PNX_ERR_INVALID, "opts is NULL");
-    const int n_all = model_n_params(o->model);
+    int n_all = model_n_params(o->model);
     if (n_all < 0) return set_error(PNX_ERR_INVALID, "unknown model %d", o->model);
+    if (o->t1_mode < 0 || o->t1_mode > 2) return set_error(PNX_ERR_INVALID, "t1_mode %d", o->t1_mode);
+    if (o->t1_mode) n_all += 1;
     if (o->n_b < 1 || o->n_b > PNX_MAX_BVALUES) return set_error(PNX_ERR_INVALID, "n_b=%d out of range [1,%d]", o->n_b, PNX_MAX_BVALUES);
     if (o->n_free < 1 || o->n_fixed < 0 || o->n_free + o->n_fixed != n_all)
         return set_error(PNX_ERR_INVALID, "n_free=%d + n_fixed=%d != %d parameters of model %d", o->n_free, o->n_fixed, n_all, o->model);

@@ -9,9 +9,9 @@
 
 namespace pnx {
 
-template <int MODEL, int N, bool FD, bool PV>
+template <int MODEL, int N, bool FD, bool PV, bool T1>
 static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stream) {
-    auto kern = curvefit_kernel<MODEL, N, FD, PV>;
+    auto kern = curvefit_kernel<MODEL, N, FD, PV, T1>;
     // LDS per block: b-value table + per wave: [n_b][64] signal tile, parked R factor and singular vectors.
     // Up to 4 waves per block; fewer when that would not fit 160 KiB.
     int waves = 4;
@@ -39,7 +39,8 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     if (args.pcov) {
         const int pb = 256;
         ColPerm cp;
-        for (int k = 0; k < kMaxP; ++k) cp.p[k] = (N == Model<MODEL>::NALL && k < 6) ? colperm<MODEL>(k) : k;
+        constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
+        for (int k = 0; k < kMaxP; ++k) cp.p[k] = (N == NP && k < Model<MODEL>::NALL) ? colperm<MODEL>(k) : k;
         hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
                            (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp);
         e = hipGetLastError();
@@ -48,24 +49,28 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     return PNX_OK;
 }
 
-template <int MODEL, int N, bool FD> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
-    return args.per_voxel ? launch_one<MODEL, N, FD, true>(args, cus, st) : launch_one<MODEL, N, FD, false>(args, cus, st);
+template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
+    return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
+}
+
+// Built per model: all parameters free (FD or analytic Jacobian) and exactly one fixed parameter (analytic, like the
+// reference: curvefit.py:274-288), each without and with the T1 / STEAM factor.
+template <int MODEL, bool T1> static int launch_t1(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
+    constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
+    if (n_free == NP) {
+        if (jac_mode == PNX_JAC_FD) return launch_pv<MODEL, NP, true, T1>(args, cus, st);
+        return launch_pv<MODEL, NP, false, T1>(args, cus, st);
+    }
+    if constexpr (NP >= 2) {
+        if (n_free == NP - 1) return launch_pv<MODEL, NP - 1, false, T1>(args, cus, st);
+    }
+    return set_error(PNX_ERR_UNSUPPORTED, "model %d%s with %d free parameters is not built (built: %d and %d)", MODEL,
+                     T1 ? "+T1" : "", n_free, NP, NP - 1);
 }
 
 template <int MODEL> static int launch_model(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
-    constexpr int NALL = Model<MODEL>::NALL;
-    if (n_free == NALL) {
-        if (jac_mode == PNX_JAC_FD) return launch_pv<MODEL, NALL, true>(args, cus, st);
-        return launch_pv<MODEL, NALL, false>(args, cus, st);
-    }
-    if constexpr (NALL >= 2) {
-        if (n_free == NALL - 1) {
-            // with fixed parameters the reference always passes the analytic Jacobian (curvefit.py:274-288)
-            return launch_pv<MODEL, NALL - 1, false>(args, cus, st);
-        }
-    }
-    return set_error(PNX_ERR_UNSUPPORTED, "model %d with %d free parameters is not built (built: %d and %d)", MODEL,
-                     n_free, NALL, NALL - 1);
+    return args.t1_mode ? launch_t1<MODEL, true>(n_free, jac_mode, args, cus, st)
+                        : launch_t1<MODEL, false>(n_free, jac_mode, args, cus, st);
 }
 
 }  // namespace pnx

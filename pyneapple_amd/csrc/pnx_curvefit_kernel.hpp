@@ -50,7 +50,8 @@ struct CurvefitArgs {
     int fixed_per_voxel;
     int max_nfev;
     int n_fixed;
-    int pad0;
+    int t1_mode;          // 0 none, 1 T1: S*(1-exp(-TR/T1)), 2 STEAM: additionally *exp(-TM/T1) (multiexp.py:210-241)
+    double tr, tm;
     double ftol, xtol, gtol;
     double p0s[kMaxP], los[kMaxP], his[kMaxP], fixeds[kMaxP];
     int free_idx[kMaxP];
@@ -581,16 +582,17 @@ template <int N> struct Park {
 //   C        trust-region step -> next x_new.
 // Register diet: bounds stay in SGPRs unless they are per voxel (PV); R (for the covariance) and the
 // singular vectors V are parked in LDS; nothing produced by the pass stays live across the next pass.
-template <int MODEL, int N, bool FD, bool PV>
+template <int MODEL, int N, bool FD, bool PV, bool T1>
 __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     using M = Model<MODEL>;
     using PK = Park<N>;
-    constexpr int NALL = M::NALL;
+    constexpr int NALL = M::NALL;            // parameters of the diffusion model
+    constexpr int NP = NALL + (T1 ? 1 : 0);  // + T1 as the last parameter (models/*.py: `names.append("T1")`)
     constexpr int NC = M::NC;
-    constexpr bool HASFIXED = (N != NALL);
+    constexpr bool HASFIXED = (N != NP);
     static_assert(!(FD && HASFIXED), "finite-difference mode is only built without fixed parameters");
     // factor column order: static per model when all parameters are free, natural order with fixed parameters
-    auto CP = [](int k) constexpr { return HASFIXED ? k : colperm<MODEL>(k); };
+    auto CP = [](int k) constexpr { return (HASFIXED || k >= NALL) ? k : colperm<MODEL>(k); };
 
     extern __shared__ double smem[];
     const int n_b = A.n_b;
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
     int state = ST_IDLE;
     long long vox = -1;
     double x[N], lb[N], ub[N];
-    double pfull[NALL];
+    double pfull[NP];
     double g[N];
     double s[N], uf[N], R2[N][N], d[N], g_h[N];
     double Vreg[PK::kParkV ? 1 : N][PK::kParkV ? 1 : N];
@@ -665,11 +667,11 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         }
         if (HASFIXED) {
 #pragma unroll
-            for (int j = 0; j < NALL; ++j) pfull[j] = 0;
+            for (int j = 0; j < NP; ++j) pfull[j] = 0;
             for (int f = 0; f < A.n_fixed; ++f) {
                 const double fv = A.fixed_per_voxel ? A.fixed[(size_t)f * A.n_vox + vox] : A.fixeds[f];
 #pragma unroll
-                for (int j = 0; j < NALL; ++j)
+                for (int j = 0; j < NP; ++j)
                     if (A.fixed_idx[f] == j) pfull[j] = fv;
             }
         }
@@ -705,10 +707,10 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
         double Rn[N][N], qn[N], gn[N], cost_new = 0;
         bool finite_f = true, yfinite = true;
         {
-            double pe[NALL];  // full parameter vector at the evaluation point
+            double pe[NP];  // full parameter vector at the evaluation point
             if (HASFIXED) {
 #pragma unroll
-                for (int j = 0; j < NALL; ++j) {
+                for (int j = 0; j < NP; ++j) {
                     pe[j] = pfull[j];
 #pragma unroll
                     for (int k = 0; k < N; ++k)
@@ -716,7 +718,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < NALL; ++j) pe[j] = xn[j];
+                for (int j = 0; j < NP; ++j) pe[j] = xn[j];
             }
             double dxv[N];
             if (FD) {
@@ -732,6 +734,25 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     if (violated && fitting) h = -h;
                     if (!fitting) h = (upper_dist >= lower_dist) ? upper_dist : -lower_dist;
                     dxv[k] = (xn[k] + h) - xn[k];  // _numdiff.py:596 "recompute dx as exactly representable number"
+                }
+            }
+            // T1 / STEAM relaxation factor (row independent): S = base * A1 [* eTM], A1 = 1 - exp(-TR/T1)
+            // (model_functions/multiexp.py:210-241); its T1 derivative analytically (multiexp.py:244-302) or as
+            // SciPy's 2-point quotient (fac(T1 + dx) - fac(T1)) / dx -- two extra exp per PASS, not per row.
+            double A1 = 1.0, eTM = 1.0, fac = 1.0, dfac = 0.0;
+            if (T1) {
+                const bool steam = A.t1_mode == 2;
+                const double T1v = pe[NALL];
+                const double eTR = exp(-A.tr / T1v);
+                A1 = 1 - eTR;
+                eTM = steam ? exp(-A.tm / T1v) : 1.0;
+                fac = A1 * eTM;
+                dfac = steam ? eTM / (T1v * T1v) * (-A.tr * eTR + A.tm * A1) : (-eTR * A.tr / (T1v * T1v));
+                if (FD) {  // T1 is the last free parameter in FD mode (no fixed parameters there)
+                    const double dx = dxv[N - 1];
+                    const double T2 = T1v + dx;
+                    const double fac2 = (1 - exp(-A.tr / T2)) * (steam ? exp(-A.tm / T2) : 1.0);
+                    dfac = (fac2 - fac) / dx;
                 }
             }
 #pragma unroll
@@ -755,10 +776,11 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                     double E[NC];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
-                    const double r0 = M::signal(pe, E) - yi;
+                    const double base = M::signal(pe, E);
+                    const double r0 = (T1 ? base * A1 * eTM : base) - yi;
                     double jr[N];
                     {
-                        double ja[NALL];
+                        double ja[NP];
                         M::jac(pe, E, bb, ja);
                         if (FD) {
                             // SciPy's 2-point quotient (f(x + dx e_k) - f(x)) / dx in closed form.  The models are
@@ -769,7 +791,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                             // relative at b = 1200) -- which is what separates its iterates from an
                             // analytic-Jacobian run -- is kept exactly.
 #pragma unroll
-                            for (int k = 0; k < N; ++k) {
+                            for (int k = 0; k < NALL; ++k) {
                                 if (comp_of_param<MODEL>(k) >= 0) {
                                     const double z = nb * dxv[k];
                                     double gz;
@@ -781,12 +803,17 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
                                 }
                             }
                         }
+                        if (T1) {
+#pragma unroll
+                            for (int k = 0; k < NALL; ++k) ja[k] *= fac;
+                            ja[NP - 1] = base * dfac;
+                        }
                         if (HASFIXED) {
 #pragma unroll
                             for (int k = 0; k < N; ++k) {
                                 jr[k] = 0;
 #pragma unroll
-                                for (int j = 0; j < NALL; ++j)
+                                for (int j = 0; j < NP; ++j)
                                     if (A.free_idx[k] == j) jr[k] = ja[j];
                             }
                         } else {

@@ -13,13 +13,27 @@ import numpy as np
 class _Parametric:
     _base_names: list[str] = []
 
-    def __init__(self, fixed_params: dict[str, float] | None = None, **model_kwargs):
+    def __init__(self, fixed_params: dict[str, float] | None = None, fit_t1: bool = False, fit_t1_steam: bool = False,
+                 repetition_time: float | None = None, mixing_time: float | None = None, **model_kwargs):
         self.model_kwargs = model_kwargs
         self.fixed_params = dict(fixed_params) if fixed_params else {}
-        self.fit_t1 = False
-        self.fit_t1_steam = False
-        self.repetition_time = None
-        self.mixing_time = None
+        if fit_t1_steam:
+            fit_t1 = True  # STEAM always implies the standard T1 factor (models/monoexp.py:38-39)
+        if fit_t1 and repetition_time is None:
+            raise ValueError("repetition_time is required when fit_t1=True.")
+        if fit_t1_steam and mixing_time is None:
+            raise ValueError("mixing_time is required when fit_t1_steam=True.")
+        self.fit_t1 = fit_t1
+        self.fit_t1_steam = fit_t1_steam
+        self.repetition_time = repetition_time
+        self.mixing_time = mixing_time
+
+    def _t1(self, signal, T1):
+        # model_functions/multiexp.py:210-241
+        signal = signal * (1 - np.exp(-self.repetition_time / T1))
+        if self.fit_t1_steam:
+            signal = signal * np.exp(-self.mixing_time / T1)
+        return signal
 
     def _validate_fixed_params(self):
         if self.fixed_params:
@@ -29,9 +43,15 @@ class _Parametric:
             if len(self.fixed_params) >= len(self._all_param_names):
                 raise ValueError("At least one parameter must remain free.")
 
+    def _base(self) -> list[str]:
+        return list(self._base_names)
+
     @property
     def _all_param_names(self) -> list[str]:
-        return list(self._base_names)
+        names = self._base()
+        if self.fit_t1 or self.fit_t1_steam:
+            names.append("T1")
+        return names
 
     @property
     def param_names(self) -> list[str]:
@@ -66,47 +86,48 @@ class MonoExpModel(_Parametric):
         self._validate_fixed_params()
 
     def forward(self, xdata, *p):
-        return p[0] * np.exp(-xdata * p[1])
+        s = p[0] * np.exp(-xdata * p[1])
+        return self._t1(s, p[2]) if self.fit_t1 else s
 
 
 class BiExpModel(_Parametric):
     """Reduced [f1,D1,D2] (default) / S0 [f1,D1,D2,S0] / full [f1,D1,f2,D2]."""
 
     def __init__(self, fit_reduced: bool = True, fit_s0: bool = False, fixed_params=None, **kw):
-        super().__init__(fixed_params, **kw)
         if fit_s0 and not fit_reduced:
             raise ValueError("fit_s0=True requires fit_reduced=True. Full model with independent fractions and S0 "
                              "is over-parameterized.")
         self.fit_reduced, self.fit_s0 = fit_reduced, fit_s0
+        super().__init__(fixed_params, **kw)
         self._validate_fixed_params()
 
-    @property
-    def _all_param_names(self):
+    def _base(self):
         if self.fit_reduced:
             return ["f1", "D1", "D2", "S0"] if self.fit_s0 else ["f1", "D1", "D2"]
         return ["f1", "D1", "f2", "D2"]
 
     def forward(self, xdata, *p):
         if self.fit_s0:
-            return p[3] * (p[0] * np.exp(-xdata * p[1]) + (1 - p[0]) * np.exp(-xdata * p[2]))
-        if self.fit_reduced:
-            return p[0] * np.exp(-xdata * p[1]) + (1 - p[0]) * np.exp(-xdata * p[2])
-        return p[0] * np.exp(-xdata * p[1]) + p[2] * np.exp(-xdata * p[3])
+            s = p[3] * (p[0] * np.exp(-xdata * p[1]) + (1 - p[0]) * np.exp(-xdata * p[2]))
+        elif self.fit_reduced:
+            s = p[0] * np.exp(-xdata * p[1]) + (1 - p[0]) * np.exp(-xdata * p[2])
+        else:
+            s = p[0] * np.exp(-xdata * p[1]) + p[2] * np.exp(-xdata * p[3])
+        return self._t1(s, p[len(self._base())]) if self.fit_t1 else s
 
 
 class TriExpModel(_Parametric):
     """Reduced [f1,D1,f2,D2,D3] (default) / S0 [...,S0] / full [f1,D1,f2,D2,f3,D3]."""
 
     def __init__(self, fit_reduced: bool = True, fit_s0: bool = False, fixed_params=None, **kw):
-        super().__init__(fixed_params, **kw)
         if fit_s0 and not fit_reduced:
             raise ValueError("fit_s0=True requires fit_reduced=True. Full model with independent fractions and S0 "
                              "is over-parameterized.")
         self.fit_reduced, self.fit_s0 = fit_reduced, fit_s0
+        super().__init__(fixed_params, **kw)
         self._validate_fixed_params()
 
-    @property
-    def _all_param_names(self):
+    def _base(self):
         if self.fit_reduced:
             return ["f1", "D1", "f2", "D2", "D3", "S0"] if self.fit_s0 else ["f1", "D1", "f2", "D2", "D3"]
         return ["f1", "D1", "f2", "D2", "f3", "D3"]
@@ -114,10 +135,12 @@ class TriExpModel(_Parametric):
     def forward(self, xdata, *p):
         e = lambda D: np.exp(-xdata * D)
         if self.fit_s0:
-            return p[5] * (p[0] * e(p[1]) + p[2] * e(p[3]) + (1 - p[0] - p[2]) * e(p[4]))
-        if self.fit_reduced:
-            return p[0] * e(p[1]) + p[2] * e(p[3]) + (1 - p[0] - p[2]) * e(p[4])
-        return p[0] * e(p[1]) + p[2] * e(p[3]) + p[4] * e(p[5])
+            s = p[5] * (p[0] * e(p[1]) + p[2] * e(p[3]) + (1 - p[0] - p[2]) * e(p[4]))
+        elif self.fit_reduced:
+            s = p[0] * e(p[1]) + p[2] * e(p[3]) + (1 - p[0] - p[2]) * e(p[4])
+        else:
+            s = p[0] * e(p[1]) + p[2] * e(p[3]) + p[4] * e(p[5])
+        return self._t1(s, p[len(self._base())]) if self.fit_t1 else s
 
 
 class NNLSModel:

@@ -51,16 +51,29 @@ def _validate_data_shapes(xdata: np.ndarray, ydata: np.ndarray):
 
 
 def kernel_model_key(model) -> str:
-    """Map a (reference or stand-in) parametric model object to the library's model id."""
+    """Map a (reference or stand-in) parametric model object to the library's model id (T1 suffix ignored)."""
     names = list(model._all_param_names)
-    if getattr(model, "fit_t1", False) or getattr(model, "fit_t1_steam", False) or (names and names[-1] == "T1"):
-        raise NotImplementedError(
-            "T1 / STEAM model variants are not built into libpnx_hip yet (SURVEY.md section 8f-3); "
-            "use the reference CurveFitSolver for them.")
+    if names and names[-1] == "T1":
+        names = names[:-1]
     for key, ref in api.MODEL_PARAM_NAMES.items():
         if names == ref:
             return key
-    raise NotImplementedError(f"model with parameters {names} is not supported by the HIP backend")
+    raise NotImplementedError(f"model with parameters {list(model._all_param_names)} is not supported by the HIP backend")
+
+
+def kernel_t1(model) -> dict:
+    """T1 / STEAM settings of a model object (models/*.py: fit_t1, fit_t1_steam, repetition_time, mixing_time)."""
+    steam = bool(getattr(model, "fit_t1_steam", False))
+    t1 = bool(getattr(model, "fit_t1", False)) or steam
+    if not t1:
+        return dict(t1_mode=0, tr=0.0, tm=0.0)
+    tr = getattr(model, "repetition_time", None)
+    tm = getattr(model, "mixing_time", None)
+    if tr is None:
+        raise ValueError("repetition_time is required when fit_t1=True.")
+    if steam and tm is None:
+        raise ValueError("mixing_time is required when fit_t1_steam=True.")
+    return dict(t1_mode=2 if steam else 1, tr=float(tr), tm=float(tm) if steam else 0.0)
 
 
 def _split(n: int, parts: int):
@@ -112,6 +125,7 @@ class HipCurveFitSolver(CurveFitBase):
                 raise ValueError(
                     "bounds must be a dict with parameter names as keys and (lower, upper) tuples as values.")
         self._kernel_model = kernel_model_key(model)  # fail early and loudly for unsupported models
+        self._kernel_t1 = kernel_t1(model)
 
     # ------------------------------------------------------------------ p0 / bounds (curvefit.py:319-392)
     def _prepare_p0_bounds(self, p0, bounds, n_pixels):
@@ -226,7 +240,7 @@ class HipCurveFitSolver(CurveFitBase):
 
     def _run(self, xdata, ydata, p0, lo, hi, per_voxel, fixed_idx, fixed_vals, jac):
         n_vox = ydata.shape[0]
-        kw = dict(max_nfev=int(self.max_iter), ftol=float(self.tol), jac=jac, fixed_idx=fixed_idx)
+        kw = dict(max_nfev=int(self.max_iter), ftol=float(self.tol), jac=jac, fixed_idx=fixed_idx, **self._kernel_t1)
         n_dev = max(1, min(self.n_gpus, n_vox))
         if n_dev == 1:
             return api.curvefit(self._kernel_model, xdata, ydata, p0, lo, hi, fixed_vals=fixed_vals,

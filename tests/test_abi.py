@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_struct_layout():
     lib = _lib.load()
     assert lib.pnx_version() == 1
-    # int32 x4 + 2*int32[8] + int32 x4 + 3 doubles
-    assert C.sizeof(_lib.CurvefitOpts) == 4 * 4 + 2 * 8 * 4 + 4 * 4 + 3 * 8
+    # int32 x4 + 2*int32[8] + int32 x6 + 5 doubles
+    assert C.sizeof(_lib.CurvefitOpts) == 4 * 4 + 2 * 8 * 4 + 6 * 4 + 5 * 8
     for m, n in enumerate([2, 3, 4, 4, 5, 6, 6]):
         assert lib.pnx_model_n_params(m) == n
     assert lib.pnx_model_n_params(99) < 0 and "unknown model" in _lib.last_error()

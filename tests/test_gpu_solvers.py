@@ -132,3 +132,17 @@ class TestNNLS:
         c0 = self._solver(reg_order=0).fit(b, y).params_["coefficients"][0]
         c2 = self._solver(reg_order=2, mu=0.5).fit(b, y).params_["coefficients"][0]
         assert tv(c2) < tv(c0)
+
+
+def test_t1_model_with_fixed_t1_map_through_the_plugin(gpu):
+    """MonoExp + T1 relaxation factor, T1 supplied as a per-pixel fixed map (reference fixture g6_mono_t1_fixed)."""
+    from conftest import load_golden
+
+    d = load_golden("g6_mono_t1_fixed")
+    model = MonoExpModel(fit_t1=True, repetition_time=3000.0)
+    s = HipCurveFitSolver(model=model, max_iter=250, tol=1e-8, p0={"S0": 1000.0, "D": 1e-3, "T1": 1000.0},
+                          bounds={"S0": (1.0, 5000.0), "D": (1e-5, 0.1), "T1": (100.0, 5000.0)})
+    s.fit(d["bvalues"], d["y"], pixel_fixed_params={"T1": d["fixed_T1"]})
+    assert set(s.params_) == {"S0", "D"}
+    got = np.stack([s.params_["S0"], s.params_["D"]], axis=1)
+    assert (np.abs(got - d["popt"]) <= 1e-8 * np.abs(d["popt"])).all()

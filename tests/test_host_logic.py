@@ -46,10 +46,15 @@ class TestModels:
     def test_kernel_model_key(self):
         assert kernel_model_key(TriExpModel()) == "tri_reduced"
         assert kernel_model_key(BiExpModel(fit_s0=True)) == "bi_s0"
-        m = MonoExpModel()
-        m.fit_t1 = True
-        with pytest.raises(NotImplementedError):
-            kernel_model_key(m)
+        from pyneapple_amd.solvers import kernel_t1
+
+        m = MonoExpModel(fit_t1=True, repetition_time=3000.0)
+        assert m.param_names == ["S0", "D", "T1"] and kernel_model_key(m) == "mono"
+        assert kernel_t1(m) == dict(t1_mode=1, tr=3000.0, tm=0.0)
+        ms = BiExpModel(fit_t1_steam=True, repetition_time=3000.0, mixing_time=20.0)
+        assert ms.param_names[-1] == "T1" and kernel_t1(ms)["t1_mode"] == 2
+        with pytest.raises(ValueError):
+            MonoExpModel(fit_t1=True)
 
     def test_nnls_model(self):
         m = NNLSModel(d_range=(1e-4, 0.1), n_bins=50)
