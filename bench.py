@@ -145,7 +145,7 @@ class NnlsLeg:
         from pyneapple_amd import synth
 
         cores = host_cores()
-        n = 128 * cores
+        n = 1536 * cores  # ~10-15 s of CPU work on 16 threads
         _, y, _ = synth.make_numpy("tri_reduced", n, self.n_b, sigma=0.01, scale=1000.0)
         O.nnls(self.basis, self.reg, y[:cores], self.cfg["max_iter"], n_threads=cores)
         t = time.perf_counter()
