@@ -182,11 +182,11 @@ def timed(leg, steps, warmup, world, dist, torch):
 
 
 def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_c_traffic.json;
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_d_traffic.json;
     FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is).  bench.py cannot run rocprofv3 around itself,
     so the figure is the one measured on this kernel and this full-size workload when the profile was taken."""
     try:
-        with open(os.path.join(HERE, "profiles", "r01_c_traffic.json")) as f:
+        with open(os.path.join(HERE, "profiles", "r01_d_traffic.json")) as f:
             t = json.load(f)
         for name, v in t.items():
             if kernel_prefix in name:
@@ -196,7 +196,7 @@ def pmc_traffic(kernel_prefix: str):
     return None
 
 
-def sweep_roofline(device, torch, n_vox_override=0, reps=10):
+def sweep_roofline(device, torch, n_vox_override=0, reps=20):
     """The LM residual/Jacobian/normal-equation sweep as a standalone HBM-streaming kernel (pnx_sweep_f32),
     triexp on the C3 volume: 232 algorithmic bytes per voxel-sweep against the HBM roofline."""
     from pyneapple_amd import api, synth
@@ -218,20 +218,30 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=10):
     for _ in range(2):
         api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    # one HIP-event pair per launch (on the launch stream): the average launch duration, free of host-side gaps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record()
+        api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
+        e1.record()
+    torch.cuda.synchronize()
+    ms_pair = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+    # the same launches back to back under one event pair: the figure rocprofv3's per-kernel average agrees with
+    # (an event pair per launch adds ~25 us of marker serialisation to a 0.24 ms kernel)
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea.record()
     for _ in range(reps):
         api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
-    e1.record()
+    eb.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = ea.elapsed_time(eb) / reps
     bytes_per = (n_b + n + ntri + n + 1) * 4
     ach = bytes_per * n_vox / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "sweep_kernel<tri_reduced,f32>", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None if n_vox_override else pmc_traffic("sweep_kernel<4, float>"),
+            "traffic": None if n_vox_override else pmc_traffic("sweep_"),
             "algorithmic_bytes_per_launch": bytes_per * n_vox, "algorithmic_bytes_per_voxel": bytes_per,
-            "kernel_ms_avg": ms, "voxel_sweeps_per_s": n_vox / (ms * 1e-3), "dtype": "f32"}
+            "kernel_ms_avg": ms, "per_launch_event_pair_ms_avg": ms_pair, "voxel_sweeps_per_s": n_vox / (ms * 1e-3), "dtype": "f32"}
 
 
 def main():
@@ -278,7 +288,7 @@ def main():
                    "full_size": not args.voxels},
         "roofline": {"bound": "hbm", "kernel": leg.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("curvefit_kernel<4, 5, true, false>") if (args.workload == "triexp" and args.jac == "fd" and not args.voxels) else None,
+                     "traffic": pmc_traffic("curvefit_kernel<4, 5, true, false, false>") if (args.workload == "triexp" and args.jac == "fd" and not args.voxels) else None,
                      "algorithmic_bytes_per_launch": leg.bytes_per_voxel * leg.n_vox,
                      "algorithmic_bytes_per_voxel": leg.bytes_per_voxel, "kernel_ms_avg": k_avg * 1e3,
                      "note": "whole-fit kernel is fp64-VALU/transcendental bound, not HBM bound (DESIGN.md section 4)"},

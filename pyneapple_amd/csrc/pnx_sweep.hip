@@ -27,6 +27,7 @@ template <typename T> struct SweepArgs {
     T *g;             // (n_all, n_vox)
     T *jtj;           // (n_tri, n_vox)
     long long n_vox;
+    long long v_first;  // generic kernel: first voxel to process (the tiles before it belong to the full-tile kernel)
     int n_b;
     T b[kMaxB];
 };
@@ -95,7 +96,25 @@ template <int MODEL, typename T> struct ModelT {
     }
 };
 
-template <int MODEL, typename T>
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int NT> __device__ inline float4 ld16(const float4 *p) {
+    if constexpr (NT & 1) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <int NT, typename T> __device__ inline T ld_in(const T *p) {
+    if constexpr (NT & 4) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int NT, typename T> __device__ inline void st_out(T *p, T v) {
+    if constexpr (NT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int MODEL, typename T, int NT>
 __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
     using MT = ModelT<MODEL, T>;
     constexpr int NALL = MT::NALL;
@@ -113,12 +132,13 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
     const long long n_tiles = (A.n_vox + kWave - 1) / kWave;
     const long long tiles_per_block = blockDim.x >> 6;
     const long long tstep = (long long)gridDim.x * tiles_per_block;
+    const long long t_first = A.v_first / kWave;
     const bool vec_ok = (n_b % VEC) == 0 && (reinterpret_cast<uintptr_t>(A.y) % 16) == 0;
     constexpr int PF = 8;  // 16-byte chunks per lane held in registers for the NEXT tile (8 KiB per wave)
     const bool pow2 = (n_b & (n_b - 1)) == 0;
     const int sh = __ffs(n_b) - 1;  // e / n_b as a shift when n_b is a power of two (no integer division)
     float4 pre[PF];
-    long long t = (long long)blockIdx.x * tiles_per_block + wave;
+    long long t = t_first + (long long)blockIdx.x * tiles_per_block + wave;
     if (vec_ok && t < n_tiles) {
         const long long v0 = t * kWave;
         const int nv = (A.n_vox - v0) < kWave ? (int)(A.n_vox - v0) : kWave;
@@ -126,7 +146,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
         const int total4 = nv * n_b / VEC;
 #pragma unroll
         for (int c = 0; c < PF; ++c)
-            if (lane + kWave * c < total4) pre[c] = src4[lane + kWave * c];
+            if (lane + kWave * c < total4) pre[c] = ld16<NT>(src4 + lane + kWave * c);
     }
     for (; t < n_tiles; t += tstep) {
         const long long v0 = t * kWave;
@@ -149,7 +169,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
             }
             for (int e = (lane + kWave * PF) * VEC; e < total; e += kWave * VEC) {
                 T tmp[VEC];
-                *reinterpret_cast<float4 *>(tmp) = *reinterpret_cast<const float4 *>(src + e);
+                *reinterpret_cast<float4 *>(tmp) = ld16<NT>(reinterpret_cast<const float4 *>(src + e));
                 const int v = e / n_b, i = e - v * n_b;
 #pragma unroll
                 for (int u = 0; u < VEC; ++u) tile[v * stride + i + u] = tmp[u];
@@ -163,7 +183,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
                 const int total4 = nvn * n_b / VEC;
 #pragma unroll
                 for (int c = 0; c < PF; ++c)
-                    if (lane + kWave * c < total4) pre[c] = src4[lane + kWave * c];
+                    if (lane + kWave * c < total4) pre[c] = ld16<NT>(src4 + lane + kWave * c);
             }
         } else {
             for (int e = lane; e < total; e += kWave) {
@@ -175,7 +195,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
         const bool live = lane < nv;
         T p[NALL];
 #pragma unroll
-        for (int k = 0; k < NALL; ++k) p[k] = live ? A.params[(size_t)k * A.n_vox + vox] : T(0);
+        for (int k = 0; k < NALL; ++k) p[k] = live ? ld_in<NT>(A.params + (size_t)k * A.n_vox + vox) : T(0);
         T cost = 0, g[NALL], H[NTRI];
 #pragma unroll
         for (int k = 0; k < NALL; ++k) g[k] = 0;
@@ -197,36 +217,156 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
             }
         }
         if (live) {
-            A.cost[vox] = T(0.5) * cost;
+            st_out<NT>(A.cost + vox, T(0.5) * cost);
 #pragma unroll
-            for (int k = 0; k < NALL; ++k) A.g[(size_t)k * A.n_vox + vox] = g[k];
+            for (int k = 0; k < NALL; ++k) st_out<NT>(A.g + (size_t)k * A.n_vox + vox, g[k]);
 #pragma unroll
-            for (int k = 0; k < NTRI; ++k) A.jtj[(size_t)k * A.n_vox + vox] = H[k];
+            for (int k = 0; k < NTRI; ++k) st_out<NT>(A.jtj + (size_t)k * A.n_vox + vox, H[k]);
         }
     }
 }
 
-template <int MODEL, typename T>
-static int launch_sweep(const SweepArgs<T> &a, int cus, hipStream_t st) {
+
+// Full-tile fast path: n_b is the compile-time NB, every tile holds 64 voxels, so the tile copy is CH = NB / VEC
+// unpredicated 16-byte loads per lane.  Software pipeline per wave: the loads of tile t+1 (signal chunks AND the
+// parameter vector) are issued right after tile t has been scattered into LDS and before its row loop, so nothing the
+// row loop or the result stores wait on sits behind them in the in-order vmcnt queue.
+template <int MODEL, typename T, int NB>
+__global__ void __launch_bounds__(256) sweep_full_kernel(const SweepArgs<T> A, const long long n_full) {
+    using MT = ModelT<MODEL, T>;
+    constexpr int NALL = MT::NALL;
+    constexpr int NTRI = NALL * (NALL + 1) / 2;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CH = NB / VEC;
+    constexpr int STRIDE = NB + 1;
+    constexpr int NT = 3;
+    extern __shared__ unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T *tile = smem + kMaxB + (size_t)wave * kWave * STRIDE;
+    T *bsh = smem;
+    for (int i = threadIdx.x; i < NB; i += blockDim.x) bsh[i] = A.b[i];
+    __syncthreads();
+    const long long tstep = (long long)gridDim.x * (blockDim.x >> 6);
+    long long t = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    float4 pre[CH];
+    T pn[NALL];
+    if (t < n_full) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(A.y + (size_t)t * kWave * NB) + lane;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) pre[c] = ld16<NT>(src4 + kWave * c);
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) pn[k] = A.params[(size_t)k * A.n_vox + t * kWave + lane];
+    }
+    // drain the prologue loads here: otherwise the loop header has to merge "loads outstanding" (entry) with "stores
+    // outstanding" (back edge) and the compiler settles on vmcnt(0) per iteration, i.e. waits for the previous tile's
+    // result stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (; t < n_full; t += tstep) {
+        const long long vox = t * kWave + lane;
+        T p[NALL];
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) p[k] = pn[k];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e = (lane + kWave * c) * VEC;
+            const int v = e / NB, i = e - v * NB;
+            T tmp[VEC];
+            *reinterpret_cast<float4 *>(tmp) = pre[c];
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) tile[v * STRIDE + i + u] = tmp[u];
+        }
+        const long long tn = t + tstep;
+        if (tn < n_full) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(A.y + (size_t)tn * kWave * NB) + lane;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) pre[c] = ld16<NT>(src4 + kWave * c);
+#pragma unroll
+            for (int k = 0; k < NALL; ++k) pn[k] = A.params[(size_t)k * A.n_vox + tn * kWave + lane];
+        }
+        T cost = 0, g[NALL], H[NTRI];
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) g[k] = 0;
+#pragma unroll
+        for (int k = 0; k < NTRI; ++k) H[k] = 0;
+        const T *row = tile + lane * STRIDE;
+#pragma unroll 8
+        for (int i = 0; i < NB; ++i) {
+            T sig, ja[NALL];
+            MT::eval(p, bsh[i], sig, ja);
+            const T r = sig - row[i];
+            cost += r * r;
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < NALL; ++a) {
+                g[a] += ja[a] * r;
+#pragma unroll
+                for (int c = a; c < NALL; ++c) H[q++] += ja[a] * ja[c];
+            }
+        }
+        st_out<NT>(A.cost + vox, T(0.5) * cost);
+#pragma unroll
+        for (int k = 0; k < NALL; ++k) st_out<NT>(A.g + (size_t)k * A.n_vox + vox, g[k]);
+#pragma unroll
+        for (int k = 0; k < NTRI; ++k) st_out<NT>(A.jtj + (size_t)k * A.n_vox + vox, H[k]);
+    }
+}
+
+template <int MODEL, typename T, int NB>
+static int launch_sweep_full(const SweepArgs<T> &a, long long n_full, int cus, int bpc, hipStream_t st) {
+    const int block = 256;
+    const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (NB + 1));
+    long long want = (n_full + 3) / 4, cap = (long long)cus * bpc;
+    const int grid = (int)(want < cap ? want : cap);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute((const void *)sweep_full_kernel<MODEL, T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_full_kernel<MODEL, T, NB>), dim3(grid), dim3(block), shmem, st, a, n_full);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PNX_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
+    return PNX_OK;
+}
+
+template <int MODEL, typename T, int NT>
+static int launch_sweep_nt(const SweepArgs<T> &a, int cus, hipStream_t st) {
     const int block = 256;
     const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (a.n_b + 1));
-    const long long n_tiles = (a.n_vox + kWave - 1) / kWave;
+    const long long n_tiles = (a.n_vox + kWave - 1) / kWave - a.v_first / kWave;
     long long want = (n_tiles + 3) / 4;
-    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 16;
+    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 32;
     long long cap = (long long)cus * bpc;  // memory-bound: ~2048 blocks, grid-stride the rest
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t ea = hipFuncSetAttribute((const void *)sweep_kernel<MODEL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t ea = hipFuncSetAttribute((const void *)sweep_kernel<MODEL, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
         attr_set = true;
     }
     if (shmem > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", a.n_b);
-    hipLaunchKernelGGL((sweep_kernel<MODEL, T>), dim3(grid), dim3(block), shmem, st, a);
+    hipLaunchKernelGGL((sweep_kernel<MODEL, T, NT>), dim3(grid), dim3(block), shmem, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
     return PNX_OK;
+}
+
+template <int MODEL, typename T> static int launch_sweep(SweepArgs<T> a, int cus, hipStream_t st) {
+    static const bool generic_only = getenv("PNX_SWEEP_GENERIC") != nullptr;
+    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 32;
+    const long long n_full = a.n_vox / kWave;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.y) % 16) == 0;
+    a.v_first = 0;
+    if (!generic_only && aligned && n_full > 0 && (a.n_b == 16 || a.n_b == 32)) {
+        const int rc = a.n_b == 32 ? launch_sweep_full<MODEL, T, 32>(a, n_full, cus, bpc, st)
+                                   : launch_sweep_full<MODEL, T, 16>(a, n_full, cus, bpc, st);
+        if (rc != PNX_OK) return rc;
+        a.v_first = n_full * kWave;  // ragged last tile, if any, goes through the generic kernel
+        if (a.v_first == a.n_vox) return PNX_OK;
+    }
+    return launch_sweep_nt<MODEL, T, 3>(a, cus, st);
 }
 
 template <typename T>
@@ -241,8 +381,12 @@ static int sweep_impl(int model, int64_t n_vox, int n_b, const T *b_host, const 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(PNX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
     if (hipSetDevice(device) != hipSuccess) return set_error(PNX_ERR_HIP, "hipSetDevice failed");
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(PNX_ERR_HIP, "hipGetDeviceProperties failed");
+    static int cu_cache[64] = {0};
+    if (device < 64 && cu_cache[device] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(PNX_ERR_HIP, "hipGetDeviceProperties failed");
+        cu_cache[device] = prop.multiProcessorCount;
+    }
     SweepArgs<T> a;
     a.y = y;
     a.params = params;
@@ -253,7 +397,7 @@ static int sweep_impl(int model, int64_t n_vox, int n_b, const T *b_host, const 
     a.n_b = n_b;
     for (int i = 0; i < n_b; ++i) a.b[i] = b_host[i];
     hipStream_t st = (hipStream_t)stream;
-    const int cus = prop.multiProcessorCount;
+    const int cus = device < 64 ? cu_cache[device] : 256;
     switch (model) {
     case 0: return launch_sweep<0, T>(a, cus, st);
     case 1: return launch_sweep<1, T>(a, cus, st);

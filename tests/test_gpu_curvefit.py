@@ -159,8 +159,9 @@ def test_full_size_properties_c3(gpu):
     assert torch.equal(sub["nfev"], full["nfev"][idx]) and torch.equal(sub["status"], full["status"][idx])
 
 
+@pytest.mark.parametrize("n_b", [24, 32])  # 24: generic kernel; 32: full-tile kernel + generic ragged tail
 @pytest.mark.parametrize("model", ["mono", "bi_reduced", "bi_s0", "bi_full", "tri_reduced", "tri_s0", "tri_full"])
-def test_sweep_kernel_matches_numpy(gpu, model):
+def test_sweep_kernel_matches_numpy(gpu, model, n_b):
     """pnx_sweep_f64 / f32: cost, J^T r and J^T J of one LM sweep against a numpy evaluation of the reference's
     model formulas and analytic Jacobians (fp64: rtol 1e-11; fp32: 2e-4 of the column scale)."""
     import torch
@@ -169,7 +170,7 @@ def test_sweep_kernel_matches_numpy(gpu, model):
 
     rng = np.random.default_rng(0)
     names = api.MODEL_PARAM_NAMES[model]
-    n_all, n_vox, n_b = len(names), 1000 + 37, 24
+    n_all, n_vox = len(names), 1000 + 37
     b = np.linspace(0, 1000, n_b)
     P = np.empty((n_all, n_vox))
     for k, nm in enumerate(names):
