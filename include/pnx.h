@@ -89,7 +89,7 @@ typedef struct pnx_curvefit_opts {
     int32_t jac_mode;                    /* pnx_jac_mode */
     int32_t t1_mode;                     /* 0 none; 1 T1: S*(1-exp(-TR/T1)); 2 STEAM: additionally *exp(-TM/T1).
                                             T1 is then one more model parameter, appended last
-                                            (model_functions/multiexp.py:210-241, models/*.py `names.append("T1")`) */
+                                            (model_functions/multiexp.py:210-241, each model class appends "T1" to its names) */
     int32_t reserved0;
     double tr;                           /* repetition time, same unit as T1 */
     double tm;                           /* mixing time (STEAM) */

@@ -11,8 +11,12 @@ b, y, _ = synth.make_numpy("tri_reduced", n, 32, sigma=0.01)
 names, p0, lo, hi = synth.shared_arrays("tri_reduced")
 api.curvefit("tri_reduced", b, y[:4096], p0, lo, hi)  # warm-up
 for want_pcov in (True, False):
-    t = time.perf_counter(); r = api.curvefit("tri_reduced", b, y, p0, lo, hi, want_pcov=want_pcov); dt = time.perf_counter() - t
-    print(f"curvefit host mode pcov={want_pcov}: {n/dt/1e6:.1f} M voxels/s ({dt*1e3:.0f} ms, converged {np.mean(r['status']>0):.4f})", flush=True)
+    best = 1e9
+    for _ in range(3):  # results are freed before the clock starts (unmapping 1 GB costs tens of ms)
+        t = time.perf_counter(); r = api.curvefit("tri_reduced", b, y, p0, lo, hi, want_pcov=want_pcov); dt = time.perf_counter() - t
+        best = min(best, dt); conv = np.mean(r['status'] > 0); del r
+    dt = best
+    print(f"curvefit host mode pcov={want_pcov}: {n/dt/1e6:.1f} M voxels/s ({dt*1e3:.0f} ms, converged {conv:.4f})", flush=True)
 bins, basis, reg = synth.nnls_matrices(32)
 m = min(n, 1 << 20)
 plan = api.NnlsPlan(basis, reg, 0)

@@ -5,7 +5,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "pnx_curvefit_kernel.hpp"
@@ -76,6 +83,203 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
         if (e != hipSuccess) return set_error(PNX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         return PNX_OK;
+    }
+};
+
+
+// ---- host-staging pipeline ------------------------------------------------------------------------------------
+// PNX_MEM_HOST calls hand over pageable numpy memory.  The volume is cut into chunks of voxels that flow through a
+// ring of device slots, one stage per host thread:
+//   IN      blocking H2D copy of chunk k into slot k % S (waits for the slot to be drained)
+//   LAUNCH  (the calling thread) enqueues the kernels of chunk k, alternating between the kernel streams so that the
+//           drain tail of one chunk overlaps the start of the next; records an event
+//   OUT     waits for the event, blocking D2H copy of chunk k into the caller's arrays
+//   TOUCH   helper threads take the first-touch page faults of the freshly allocated result arrays ahead of OUT
+//           (42 ms per GB when they are taken serially inside the D2H copy)
+// so H2D, compute, D2H and the page faults overlap; the call returns when every stage has drained.
+struct PipeOps {
+    std::function<int(int k, int slot, hipStream_t st)> h2d, launch, d2h;
+    std::function<void(int k)> touch;  // may be empty
+};
+
+static int run_pipeline(int n_chunks, int n_slots, int k_streams, int touchers, int device, hipStream_t user_stream,
+                        const PipeOps &ops) {
+    if (n_chunks == 1) {  // small batch: everything on the caller's stream, no threads
+        int rc = ops.h2d(0, 0, user_stream);
+        if (!rc) rc = ops.launch(0, 0, user_stream);
+        if (rc) return rc;
+        if (ops.touch) ops.touch(0);
+        PNX_HIP(hipStreamSynchronize(user_stream));
+        rc = ops.d2h(0, 0, user_stream);
+        if (rc) return rc;
+        PNX_HIP(hipStreamSynchronize(user_stream));
+        return PNX_OK;
+    }
+    if (user_stream) PNX_HIP(hipStreamSynchronize(user_stream));
+    const bool trace = getenv("PNX_HOST_TRACE") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    std::vector<double> t_in(n_chunks), t_launch(n_chunks), t_kdone(n_chunks), t_out(n_chunks), t_touch(n_chunks);
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        int in_done = 0, launched = 0, drained = 0;
+        int code = PNX_OK;
+        std::string msg;
+        bool failed = false;
+    } sh;
+    std::atomic<bool> stop(false);
+    auto fail = [&](int code) {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        if (!sh.failed) {
+            sh.failed = true;
+            sh.code = code;
+            sh.msg = g_err;  // the failing thread's message
+        }
+        stop.store(true);
+        sh.cv.notify_all();
+    };
+    hipStream_t s_in = nullptr, s_out = nullptr, s_k[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev(n_chunks, nullptr);
+    auto cleanup = [&]() {
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        for (auto &q : s_k)
+            if (q) (void)hipStreamDestroy(q);
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+    {
+        hipError_t e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
+        for (int i = 0; i < k_streams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&s_k[i], hipStreamNonBlocking);
+        for (int k = 0; k < n_chunks && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            cleanup();
+            return set_error(PNX_ERR_HIP, "pipeline stream/event setup: %s", hipGetErrorString(e));
+        }
+    }
+    // claim[k]: 0 untouched, 1 being touched / touched by a helper, 2 taken by OUT without touching
+    std::vector<std::atomic<int>> claim(n_chunks), touched(n_chunks);
+    for (int k = 0; k < n_chunks; ++k) {
+        claim[k].store(0);
+        touched[k].store(0);
+    }
+    std::vector<std::thread> th;
+    th.emplace_back([&]() {  // IN
+        if (hipSetDevice(device) != hipSuccess) return fail(set_error(PNX_ERR_HIP, "hipSetDevice failed (IN thread)"));
+        for (int k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return sh.failed || sh.drained > k - n_slots; });
+                if (sh.failed) return;
+            }
+            int rc = ops.h2d(k, k % n_slots, s_in);
+            if (!rc && hipStreamSynchronize(s_in) != hipSuccess) rc = set_error(PNX_ERR_HIP, "H2D of chunk %d failed", k);
+            if (rc) return fail(rc);
+            t_in[k] = now();
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.in_done = k + 1;
+            sh.cv.notify_all();
+        }
+    });
+    th.emplace_back([&]() {  // OUT
+        if (hipSetDevice(device) != hipSuccess) return fail(set_error(PNX_ERR_HIP, "hipSetDevice failed (OUT thread)"));
+        for (int k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return sh.failed || sh.launched > k; });
+                if (sh.failed) return;
+            }
+            if (ops.touch) {
+                int expect = 0;
+                if (claim[k].compare_exchange_strong(expect, 1)) {  // no helper got here yet: touch it ourselves
+                    ops.touch(k);
+                    touched[k].store(1);
+                } else {
+                    while (!touched[k].load()) std::this_thread::yield();
+                }
+            }
+            int rc = PNX_OK;
+            t_touch[k] = now();
+            if (hipEventSynchronize(ev[k]) != hipSuccess) rc = set_error(PNX_ERR_HIP, "kernel of chunk %d failed", k);
+            t_kdone[k] = now();
+            if (!rc) rc = ops.d2h(k, k % n_slots, s_out);
+            if (!rc && hipStreamSynchronize(s_out) != hipSuccess) rc = set_error(PNX_ERR_HIP, "D2H of chunk %d failed", k);
+            if (rc) return fail(rc);
+            t_out[k] = now();
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.drained = k + 1;
+            sh.cv.notify_all();
+        }
+    });
+    if (ops.touch)
+        for (int t = 0; t < touchers; ++t)
+            th.emplace_back([&]() {
+                for (int k = 0; k < n_chunks; ++k) {
+                    if (stop.load()) return;
+                    int expect = 0;
+                    if (claim[k].compare_exchange_strong(expect, 1)) {
+                        ops.touch(k);
+                        touched[k].store(1);
+                    }
+                }
+            });
+    // LAUNCH stage on the calling thread
+    for (int k = 0; k < n_chunks; ++k) {
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv.wait(lk, [&] { return sh.failed || sh.in_done > k; });
+            if (sh.failed) break;
+        }
+        hipStream_t st = s_k[k % k_streams];
+        int rc = ops.launch(k, k % n_slots, st);
+        if (!rc && hipEventRecord(ev[k], st) != hipSuccess) rc = set_error(PNX_ERR_HIP, "hipEventRecord failed");
+        if (rc) {
+            fail(rc);
+            break;
+        }
+        t_launch[k] = now();
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.launched = k + 1;
+        sh.cv.notify_all();
+    }
+    for (auto &t : th) t.join();
+    for (int i = 0; i < k_streams; ++i) (void)hipStreamSynchronize(s_k[i]);  // nothing of ours may outlive the call
+    cleanup();
+    if (trace)
+        for (int k = 0; k < n_chunks; ++k)
+            fprintf(stderr, "[pnx host] chunk %d: h2d_done %.1f launched %.1f out_ready %.1f kernel_done %.1f d2h_done %.1f ms\n", k, t_in[k],
+                    t_launch[k], t_touch[k], t_kdone[k], t_out[k]);
+    if (sh.failed) return set_error(sh.code, "%s", sh.msg.c_str());
+    return PNX_OK;
+}
+
+// write one byte per page of [p, p + bytes): first-touch faults taken here, in parallel with the running kernel,
+// instead of serially inside the D2H copy.  Only bytes inside the range are written (the range is this chunk's own
+// slice of a result array, about to be overwritten by its D2H copy).
+static void touch_pages(void *p, size_t bytes) {
+    if (!p || !bytes) return;
+    volatile char *c = (volatile char *)p;
+    const uintptr_t a = (uintptr_t)p;
+    c[0] = 0;
+    for (size_t off = (4096 - (a & 4095)) & 4095; off < bytes; off += 4096) c[off] = 0;
+}
+
+static int env_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const long v = atol(e);
+    return v < lo ? lo : (v > hi ? hi : (int)v);
+}
+
+struct Carver {  // hands out 256-byte aligned pieces of one device slab
+    char *base = nullptr;
+    size_t off = 0;
+    void *take(size_t bytes) {
+        void *p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
     }
 };
 
@@ -228,50 +432,99 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     if (mem == PNX_MEM_DEVICE)
         return curvefit_device(o, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, dev, (hipStream_t)stream);
 
-    // ---- host staging (synchronous).  TODO(next): chunked double-buffered streams for volumes > HBM share.
-    hipStream_t st = (hipStream_t)stream;
-    DevBuf dy, dp0, dlo, dhi, dfx, dpopt, dpcov, dstat, dnfev, dcost;
+    // ---- host staging: chunk ring (run_pipeline above)
     const size_t nv = (size_t)n_vox;
-    if ((rc = dy.alloc(nv * o->n_b * sizeof(double)))) return rc;
-    PNX_HIP(hipMemcpyAsync(dy.p, y, nv * o->n_b * sizeof(double), hipMemcpyHostToDevice, st));
-    const double *p0_d = p0, *lo_d = lo, *hi_d = hi, *fx_d = fixed;
-    if (o->per_voxel_p0_bounds) {
-        const size_t bytes = nv * n * sizeof(double);
-        if ((rc = dp0.alloc(bytes)) || (rc = dlo.alloc(bytes)) || (rc = dhi.alloc(bytes))) return rc;
-        PNX_HIP(hipMemcpyAsync(dp0.p, p0, bytes, hipMemcpyHostToDevice, st));
-        PNX_HIP(hipMemcpyAsync(dlo.p, lo, bytes, hipMemcpyHostToDevice, st));
-        PNX_HIP(hipMemcpyAsync(dhi.p, hi, bytes, hipMemcpyHostToDevice, st));
-        p0_d = (const double *)dp0.p;
-        lo_d = (const double *)dlo.p;
-        hi_d = (const double *)dhi.p;
+    const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", 3 << 18, 1024, 1 << 26);
+    const int n_chunks = (int)((nv + chunk - 1) / chunk);
+    const int n_slots = n_chunks < 3 ? n_chunks : env_int("PNX_HOST_SLOTS", 3, 2, 8);
+    const size_t cap = nv < chunk ? nv : chunk;
+    const bool pv = o->per_voxel_p0_bounds != 0, fpv = o->n_fixed && o->fixed_per_voxel;
+    const bool need_stat = status || pcov, need_cost = cost || pcov;
+    struct Slot {
+        DevBuf slab;
+        double *y = nullptr, *p0 = nullptr, *lo = nullptr, *hi = nullptr, *fx = nullptr, *popt = nullptr, *pcov = nullptr,
+               *cost = nullptr;
+        int8_t *stat = nullptr;
+        int32_t *nfev = nullptr;
+    };
+    std::vector<Slot> slots(n_slots);
+    for (int w = 0; w < n_slots; ++w) {
+        Slot &S = slots[w];
+        for (int pass = 0; pass < 2; ++pass) {  // pass 0 sizes the slab, pass 1 carves it
+            Carver c;
+            c.base = (char *)S.slab.p;
+            S.y = (double *)c.take(cap * o->n_b * sizeof(double));
+            if (pv) {
+                S.p0 = (double *)c.take(cap * n * sizeof(double));
+                S.lo = (double *)c.take(cap * n * sizeof(double));
+                S.hi = (double *)c.take(cap * n * sizeof(double));
+            }
+            if (fpv) S.fx = (double *)c.take(cap * o->n_fixed * sizeof(double));
+            S.popt = (double *)c.take(cap * n * sizeof(double));
+            if (pcov) S.pcov = (double *)c.take(cap * n * n * sizeof(double));
+            if (need_stat) S.stat = (int8_t *)c.take(cap);
+            if (nfev) S.nfev = (int32_t *)c.take(cap * sizeof(int32_t));
+            if (need_cost) S.cost = (double *)c.take(cap * sizeof(double));
+            if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
+        }
     }
-    if (o->n_fixed && o->fixed_per_voxel) {
-        const size_t bytes = nv * o->n_fixed * sizeof(double);
-        if ((rc = dfx.alloc(bytes))) return rc;
-        PNX_HIP(hipMemcpyAsync(dfx.p, fixed, bytes, hipMemcpyHostToDevice, st));
-        fx_d = (const double *)dfx.p;
-    }
-    if ((rc = dpopt.alloc(nv * n * sizeof(double)))) return rc;
-    if (pcov && (rc = dpcov.alloc(nv * n * n * sizeof(double)))) return rc;
-    if ((status || pcov) && (rc = dstat.alloc(nv))) return rc;
-    if (nfev && (rc = dnfev.alloc(nv * sizeof(int32_t)))) return rc;
-    if ((cost || pcov) && (rc = dcost.alloc(nv * sizeof(double)))) return rc;
-    rc = curvefit_device(o, n_vox, b, (const double *)dy.p, p0_d, lo_d, hi_d, fx_d, (double *)dpopt.p,
-                         pcov ? (double *)dpcov.p : nullptr, (status || pcov) ? (int8_t *)dstat.p : nullptr,
-                         nfev ? (int32_t *)dnfev.p : nullptr, (cost || pcov) ? (double *)dcost.p : nullptr, dev, st);
-    if (rc) return rc;
-    PNX_HIP(hipMemcpyAsync(popt, dpopt.p, nv * n * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (pcov) PNX_HIP(hipMemcpyAsync(pcov, dpcov.p, nv * n * n * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (status) PNX_HIP(hipMemcpyAsync(status, dstat.p, nv, hipMemcpyDeviceToHost, st));
-    if (nfev) PNX_HIP(hipMemcpyAsync(nfev, dnfev.p, nv * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (cost) PNX_HIP(hipMemcpyAsync(cost, dcost.p, nv * sizeof(double), hipMemcpyDeviceToHost, st));
-    PNX_HIP(hipStreamSynchronize(st));
-    return PNX_OK;
+    auto span = [&](int k, size_t &v0, size_t &c) {
+        v0 = (size_t)k * chunk;
+        c = (nv - v0) < chunk ? (nv - v0) : chunk;
+    };
+    PipeOps ops;
+    ops.h2d = [&](int k, int slot, hipStream_t st) -> int {
+        Slot &S = slots[slot];
+        size_t v0, c;
+        span(k, v0, c);
+        PNX_HIP(hipMemcpyAsync(S.y, y + v0 * o->n_b, c * o->n_b * sizeof(double), hipMemcpyHostToDevice, st));
+        // parameter-major (k, n_vox) arrays: one row slice per parameter, device stride = c
+        if (pv)
+            for (int j = 0; j < n; ++j) {
+                PNX_HIP(hipMemcpyAsync(S.p0 + j * c, p0 + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.lo + j * c, lo + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.hi + j * c, hi + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+            }
+        if (fpv)
+            for (int j = 0; j < o->n_fixed; ++j)
+                PNX_HIP(hipMemcpyAsync(S.fx + j * c, fixed + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+        return PNX_OK;
+    };
+    ops.launch = [&](int k, int slot, hipStream_t st) -> int {
+        Slot &S = slots[slot];
+        size_t v0, c;
+        span(k, v0, c);
+        return curvefit_device(o, (int64_t)c, b, S.y, pv ? S.p0 : p0, pv ? S.lo : lo, pv ? S.hi : hi, fpv ? S.fx : fixed,
+                               S.popt, pcov ? S.pcov : nullptr, S.stat, S.nfev, S.cost, dev, st);
+    };
+    ops.touch = [&](int k) {
+        size_t v0, c;
+        span(k, v0, c);
+        for (int j = 0; j < n; ++j) touch_pages(popt + j * nv + v0, c * sizeof(double));
+        if (pcov) touch_pages(pcov + v0 * n * n, c * n * n * sizeof(double));
+        if (status) touch_pages(status + v0, c);
+        if (nfev) touch_pages(nfev + v0, c * sizeof(int32_t));
+        if (cost) touch_pages(cost + v0, c * sizeof(double));
+    };
+    ops.d2h = [&](int k, int slot, hipStream_t st) -> int {
+        Slot &S = slots[slot];
+        size_t v0, c;
+        span(k, v0, c);
+        for (int j = 0; j < n; ++j)
+            PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, S.popt + j * c, c * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, S.pcov, c * n * n * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (status) PNX_HIP(hipMemcpyAsync(status + v0, S.stat, c, hipMemcpyDeviceToHost, st));
+        if (nfev) PNX_HIP(hipMemcpyAsync(nfev + v0, S.nfev, c * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.cost, c * sizeof(double), hipMemcpyDeviceToHost, st));
+        return PNX_OK;
+    };
+    return run_pipeline(n_chunks, n_slots, 2, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), device, (hipStream_t)stream, ops);
 }
 
 // ------------------------------------------------------------------------------------------- NNLS
 struct pnx_nnls_plan {
     NnlsPlanData d;
+    std::mutex mu;  // the plan's device scratch (ATY chunk, M overflow, queue) serves one solve at a time
 };
 
 int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
@@ -313,28 +566,73 @@ int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int 
     hipStream_t st = (hipStream_t)stream;
     if (max_iter <= 0) max_iter = 3 * P.n_bins;  // scipy/optimize/_nnls.py:93-94
     if (mem == PNX_MEM_DEVICE) return nnls_solve_device(&P, n_vox, y, max_iter, coeff, rnorm, status, iters, st);
+    // host staging: the same chunk ring as the curve fit, with ONE kernel stream -- the plan's device scratch (ATY
+    // chunk, M overflow, queue) serves one solve at a time, and in-order launches on one stream guarantee that.
+    // The (n_vox, n_bins) coefficient array is 8.4 GB for the C4 volume: its D2H and first-touch faults hide behind
+    // the solves of the following chunks.
+    std::lock_guard<std::mutex> plan_lock(plan->mu);
     const size_t nv = (size_t)n_vox;
-    // chunked so that scratch + staged outputs stay bounded
-    const size_t chunk = 1u << 18;
-    DevBuf dy, dc, dr, ds, di;
+    const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 1 << 18, 1024, 1 << 22);
+    const int n_chunks = (int)((nv + chunk - 1) / chunk);
+    const int n_slots = n_chunks < 3 ? n_chunks : 3;
+    const size_t cap = nv < chunk ? nv : chunk;
+    struct Slot {
+        DevBuf slab;
+        double *y = nullptr, *c = nullptr, *r = nullptr;
+        int8_t *s = nullptr;
+        int32_t *i = nullptr;
+    };
+    std::vector<Slot> slots(n_slots);
     int rc;
-    const size_t cn = nv < chunk ? nv : chunk;
-    if ((rc = dy.alloc(cn * P.n_meas * sizeof(double))) || (rc = dc.alloc(cn * P.n_bins * sizeof(double))) ||
-        (rc = dr.alloc(cn * sizeof(double))) || (rc = ds.alloc(cn)) || (rc = di.alloc(cn * sizeof(int32_t))))
-        return rc;
-    for (size_t off = 0; off < nv; off += chunk) {
-        const size_t c = (nv - off) < chunk ? (nv - off) : chunk;
-        PNX_HIP(hipMemcpyAsync(dy.p, y + off * P.n_meas, c * P.n_meas * sizeof(double), hipMemcpyHostToDevice, st));
-        rc = nnls_solve_device(&P, (int64_t)c, (const double *)dy.p, max_iter, (double *)dc.p, (double *)dr.p,
-                               (int8_t *)ds.p, (int32_t *)di.p, st);
-        if (rc) return rc;
-        PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, dc.p, c * P.n_bins * sizeof(double), hipMemcpyDeviceToHost, st));
-        PNX_HIP(hipMemcpyAsync(rnorm + off, dr.p, c * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (status) PNX_HIP(hipMemcpyAsync(status + off, ds.p, c, hipMemcpyDeviceToHost, st));
-        if (iters) PNX_HIP(hipMemcpyAsync(iters + off, di.p, c * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        PNX_HIP(hipStreamSynchronize(st));
+    for (int w = 0; w < n_slots; ++w) {
+        Slot &S = slots[w];
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)S.slab.p;
+            S.y = (double *)c.take(cap * P.n_meas * sizeof(double));
+            S.c = (double *)c.take(cap * P.n_bins * sizeof(double));
+            S.r = (double *)c.take(cap * sizeof(double));
+            S.s = (int8_t *)c.take(cap);
+            S.i = (int32_t *)c.take(cap * sizeof(int32_t));
+            if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
+        }
     }
-    return PNX_OK;
+    auto span = [&](int k, size_t &off, size_t &c) {
+        off = (size_t)k * chunk;
+        c = (nv - off) < chunk ? (nv - off) : chunk;
+    };
+    PipeOps ops;
+    ops.h2d = [&](int k, int slot, hipStream_t s) -> int {
+        size_t off, c;
+        span(k, off, c);
+        PNX_HIP(hipMemcpyAsync(slots[slot].y, y + off * P.n_meas, c * P.n_meas * sizeof(double), hipMemcpyHostToDevice, s));
+        return PNX_OK;
+    };
+    ops.launch = [&](int k, int slot, hipStream_t s) -> int {
+        Slot &S = slots[slot];
+        size_t off, c;
+        span(k, off, c);
+        return nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
+    };
+    ops.touch = [&](int k) {
+        size_t off, c;
+        span(k, off, c);
+        touch_pages(coeff + off * P.n_bins, c * P.n_bins * sizeof(double));
+        touch_pages(rnorm + off, c * sizeof(double));
+        if (status) touch_pages(status + off, c);
+        if (iters) touch_pages(iters + off, c * sizeof(int32_t));
+    };
+    ops.d2h = [&](int k, int slot, hipStream_t s) -> int {
+        Slot &S = slots[slot];
+        size_t off, c;
+        span(k, off, c);
+        PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, S.c, c * P.n_bins * sizeof(double), hipMemcpyDeviceToHost, s));
+        PNX_HIP(hipMemcpyAsync(rnorm + off, S.r, c * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (status) PNX_HIP(hipMemcpyAsync(status + off, S.s, c, hipMemcpyDeviceToHost, s));
+        if (iters) PNX_HIP(hipMemcpyAsync(iters + off, S.i, c * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        return PNX_OK;
+    };
+    return run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
 }
 
 int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,

@@ -20,7 +20,10 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     if (bytes(waves) > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", args.n_b);
     const int block = waves * kWave;
     const size_t shmem = bytes(waves);
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};  // function attributes are per device
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool &attr_set = attr_done[cur_dev & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));

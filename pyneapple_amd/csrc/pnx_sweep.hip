@@ -318,7 +318,10 @@ static int launch_sweep_full(const SweepArgs<T> &a, long long n_full, int cus, i
     const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (NB + 1));
     long long want = (n_full + 3) / 4, cap = (long long)cus * bpc;
     const int grid = (int)(want < cap ? want : cap);
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};  // function attributes are per device
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool &attr_set = attr_done[cur_dev & 63];
     if (!attr_set) {
         hipError_t ea = hipFuncSetAttribute((const void *)sweep_full_kernel<MODEL, T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
@@ -340,7 +343,10 @@ static int launch_sweep_nt(const SweepArgs<T> &a, int cus, hipStream_t st) {
     long long cap = (long long)cus * bpc;  // memory-bound: ~2048 blocks, grid-stride the rest
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};  // function attributes are per device
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool &attr_set = attr_done[cur_dev & 63];
     if (!attr_set) {
         hipError_t ea = hipFuncSetAttribute((const void *)sweep_kernel<MODEL, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea != hipSuccess) return set_error(PNX_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));

@@ -258,3 +258,30 @@ def test_t1_models_match_oracle(gpu, oracle, model, t1_mode, jac):
     assert same.mean() > 0.9
     np.testing.assert_allclose(r["cost"], o["cost"], rtol=1e-4, atol=1e-300)
     assert (rel_err(r["popt"], o["popt"]).max(axis=0)[same] <= 1e-4).mean() > 0.97
+
+
+def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
+    """PNX_MEM_HOST staging cuts the volume into chunks that flow through a ring of device slots (IN / launch / OUT / page-touch threads): a ragged chunking of a
+    batch with per-voxel p0/bounds and a per-voxel fixed map must return what the single-chunk call returns."""
+    from pyneapple_amd import synth
+
+    n_vox = 5000 + 37
+    b, y, P = synth.make_numpy("bi_reduced", n_vox, 24, sigma=0.01, seed=5)
+    rng = np.random.default_rng(5)
+    names, p0s, los, his = synth.shared_arrays("bi_reduced")
+    # free: f1, D2; fixed: D1 per voxel (analytic-Jacobian path, like SegmentedFitter's second step)
+    p0 = np.tile(p0s[[0, 2], None], (1, n_vox)) * rng.uniform(0.9, 1.1, (2, n_vox))
+    lo = np.tile(los[[0, 2], None], (1, n_vox))
+    hi = np.tile(his[[0, 2], None], (1, n_vox))
+    fixed = P["D1"][None, :].copy()
+    kw = dict(fixed_idx=[1], fixed_vals=fixed, jac="analytic")
+    monkeypatch.setenv("PNX_HOST_CHUNK", str(1 << 20))
+    one = gpu.curvefit("bi_reduced", b, y, p0, lo, hi, **kw)
+    monkeypatch.setenv("PNX_HOST_CHUNK", "1024")
+    for slots, touchers in (("2", "0"), ("4", "3")):
+        monkeypatch.setenv("PNX_HOST_SLOTS", slots)
+        monkeypatch.setenv("PNX_HOST_TOUCHERS", touchers)
+        many = gpu.curvefit("bi_reduced", b, y, p0, lo, hi, **kw)
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            np.testing.assert_array_equal(many[k], one[k], err_msg=k)
+    assert (one["status"] > 0).mean() > 0.99

@@ -114,3 +114,19 @@ def test_full_size_kkt_c4(gpu):
     if bool(bad.any()):
         assert bool((coeff[bad] == 0).all())
         torch.testing.assert_close(rnorm[bad], torch.linalg.norm(y[bad], dim=1))
+
+
+def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
+    """Chunked, pipelined host staging (solves in order on one stream) returns the single-chunk results."""
+    from pyneapple_amd import synth
+
+    _, basis, reg = synth.nnls_matrices(32)
+    _, y, _ = synth.make_numpy("tri_reduced", 3000 + 11, 32, sigma=0.01, seed=3, scale=1000.0)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    one = plan.solve(y, 250)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "1024")
+    many = plan.solve(y, 250)
+    plan.close()
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many[k], one[k], err_msg=k)
+    assert (one["status"] == 1).all()
