@@ -196,6 +196,61 @@ def pmc_traffic(kernel_prefix: str):
     return None
 
 
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (MI355X_MICROARCH.md: half the 157.3 TF fp32 rate)
+
+
+def pmc_flops(kernel_prefix: str):
+    """fp64 flop per voxel ISSUED by the kernel (64 lanes per fp64 VALU instruction, FMA = 2), from the committed
+    PMC pass (profiles/r01_d_pmc_*.txt -> profiles/r01_d_flops.json)."""
+    try:
+        with open(os.path.join(HERE, "profiles", "r01_d_flops.json")) as f:
+            t = json.load(f)
+        for name, v in t.items():
+            if kernel_prefix in name:
+                return v
+    except Exception:
+        pass
+    return None
+
+
+def mfma_roofline(device, torch, reps=20):
+    """The NNLS Gram step (aty = y . basis on v_mfma_f64_16x16x4) alone, 2^20 voxels x 32 b-values x 250 bins:
+    algorithmic flops 2 * n_vox * n_b * n_bins per launch against the fp64 matrix peak."""
+    from pyneapple_amd import api, synth
+
+    n_vox, n_b = 1 << 20, 32
+    _, basis, reg = synth.nnls_matrices(n_b)
+    plan = api.NnlsPlan(basis, reg, device.index)
+    _, y = synth.make_torch("tri_reduced", n_vox, n_b, device, sigma=0.01, scale=1000.0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        plan.aty_device(n_vox, y, None, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.aty_device(n_vox, y, None, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    plan.close()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * n_vox * n_b * basis.shape[1]
+    ach = flops / (ms * 1e-3) / 1e12
+    out_bytes = n_vox * 256 * 8 + n_vox * n_b * 8
+    return {"bound": "mfma", "kernel": "nnls_aty_mfma_kernel (v_mfma_f64_16x16x4_f64)", "achieved": ach,
+            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": pmc_traffic("nnls_aty_mfma_kernel"),
+            "algorithmic_flop_per_launch": flops, "kernel_ms_avg": ms, "dtype": "f64",
+            "hbm_GBps": out_bytes / (ms * 1e-3) / 1e9,
+            "note": "fp64 because an fp32 Gram product breaks NNLS parity (DESIGN.md 4.3); the (n_vox,256) fp64 product is "
+                    "materialised, so the step is co-bound by its HBM write"}
+
+
+def nnls_traffic(n_vox):
+    """PMC HBM bytes of one NNLS step: the per-launch figure (one 2^20-voxel chunk) times the chunks per step."""
+    t = pmc_traffic("nnls_kernel")
+    return None if t is None else t * ((n_vox + (1 << 20) - 1) >> 20)
+
+
 def sweep_roofline(device, torch, n_vox_override=0, reps=20):
     """The LM residual/Jacobian/normal-equation sweep as a standalone HBM-streaming kernel (pnx_sweep_f32),
     triexp on the C3 volume: 232 algorithmic bytes per voxel-sweep against the HBM roofline."""
@@ -294,6 +349,12 @@ def main():
                      "note": "whole-fit kernel is fp64-VALU/transcendental bound, not HBM bound (DESIGN.md section 4)"},
         "check": leg.check(),
     }
+    fl = pmc_flops("curvefit_kernel<4, 5, true, false, false>") if (args.workload == "triexp" and args.jac == "fd") else None
+    if fl:  # the bound that actually applies: fp64 VALU issue (flop count from the committed PMC pass, time live)
+        tf = fl["fp64_flop_per_voxel_issued"] * leg.n_vox / k_avg / 1e12
+        out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                                       "fp64_flop_per_voxel_issued": fl["fp64_flop_per_voxel_issued"],
+                                       "lane_utilisation": fl["lane_utilisation"], "source": "profiles/r01_d_flops.json"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = leg.cpu_baseline()
     if args.workload == "triexp" and not args.no_secondary:
@@ -307,12 +368,15 @@ def main():
         sec = {"workload": "NNLS reg_order=2 mu=0.02 n_bins=250, 256x256x64x32, fp64", "value": leg2.n_vox * world * steps2 / dt2,
                "unit": "voxels/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "check": leg2.check(),
                "roofline": {"bound": "hbm", "kernel": "nnls_kernel", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach2 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel}}
+                            "frac": ach2 / HBM_PEAK_GBS, "traffic": nnls_traffic(leg2.n_vox) if not args.voxels else None,
+                            "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel, "kernel_ms_avg": k2avg * 1e3,
+                            "note": "active-set loop is latency / VALU-issue / L2-bandwidth bound (DESIGN.md 4.3)"}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec
     if args.workload == "triexp" and not args.no_secondary:
         out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
+        out["roofline_mfma"] = mfma_roofline(device, torch)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

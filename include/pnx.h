@@ -144,6 +144,14 @@ int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
 int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
                        double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
 
+/*
+ * The MFMA Gram step of the NNLS path on its own: aty (n_vox, 256) = y (n_vox, n_meas) . basis (n_meas, n_bins),
+ * columns >= n_bins zero (the layout the active-set kernel consumes).  Device pointers only; n_vox <= 2^20 per call.
+ * This is the batched-GEMM part of what NNLSSolver._fit_single_pixel hands to scipy.optimize.nnls per voxel
+ * (nnls_solver.py:195-197: A^T y of the normal equations); exposed so that it can be timed and checked by itself.
+ */
+int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream);
+
 /* One-shot convenience: plan_create + solve + plan_destroy with host pointers. */
 int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                        const double *y, int max_iter, double *coeff, double *rnorm, int8_t *status,

@@ -131,6 +131,10 @@ class NnlsPlan:
         check(load().pnx_nnls_solve_f64(self._h, int(n_vox), ptr(y), int(max_iter), ptr(coeff), ptr(rnorm),
                                         ptr(status), ptr(iters), MEM_DEVICE, stream))
 
+    def aty_device(self, n_vox, y, aty=None, stream=None):
+        """Enqueue the MFMA Gram step alone: aty (n_vox, 256) = y @ basis (None: into the plan's own scratch)."""
+        check(load().pnx_nnls_aty_f64(self._h, int(n_vox), ptr(y), ptr(aty), stream))
+
     def close(self):
         if self._h:
             load().pnx_nnls_plan_destroy(self._h)

@@ -635,6 +635,14 @@ int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int 
     return run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
 }
 
+int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream) {
+    if (!plan) return set_error(PNX_ERR_INVALID, "plan is NULL");
+    if (n_vox < 0 || (n_vox && !y_dev)) return set_error(PNX_ERR_INVALID, "NULL data pointer");
+    if (n_vox == 0) return PNX_OK;
+    PNX_HIP(hipSetDevice(plan->d.device));
+    return nnls_aty_device(&plan->d, n_vox, y_dev, aty_dev, (hipStream_t)stream);
+}
+
 int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                        const double *y, int max_iter, double *coeff, double *rnorm, int8_t *status, int32_t *iters,
                        int device) {

@@ -819,6 +819,21 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
     return PNX_OK;
 }
 
+int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream) {
+    if (!P->aty) return set_error(PNX_ERR_UNSUPPORTED, "the MFMA Gram step is disabled for this plan (n_meas=%d)", P->n_meas);
+    if (n_vox > kAtyChunk) return set_error(PNX_ERR_INVALID, "n_vox=%lld > %d per call", (long long)n_vox, kAtyChunk);
+    const int kpad = (P->n_meas + 3) & ~3;
+    const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);
+    const long long strips = (n_vox + 15) / 16;
+    long long grid = (strips + 3) / 4;
+    const long long cap = (long long)P->cus * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(nnls_aty_mfma_kernel, dim3((unsigned)grid), dim3(256), lds, stream, y_d, P->Bp, aty_d ? aty_d : P->aty,
+                       (long long)n_vox, P->n_meas);
+    PNX_HIPN(hipGetLastError());
+    return PNX_OK;
+}
+
 int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis) {
     double *db = nullptr, *dbin = nullptr, *dout = nullptr;
     PNX_HIPN(hipMalloc(&db, n_meas * sizeof(double)));

@@ -28,6 +28,7 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
 void nnls_plan_free(NnlsPlanData *P);
 int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d,
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream);
 int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis);
 
 }  // namespace pnx

@@ -74,6 +74,27 @@ def test_builders_on_device(gpu):
     np.testing.assert_allclose(basis, d["basis"], rtol=4e-16, atol=0)  # exp() within 1-2 ulp of numpy's
 
 
+def test_mfma_gram_step_matches_numpy(gpu):
+    """pnx_nnls_aty_f64 (v_mfma_f64_16x16x4 Gram step): aty = y @ basis to fp64 rounding, padding columns zero."""
+    import torch
+
+    from pyneapple_amd import synth
+
+    _, basis, reg = synth.nnls_matrices(32)
+    _, y, _ = synth.make_numpy("tri_reduced", 1000 + 13, 32, sigma=0.01, seed=1, scale=1000.0)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    dev = torch.device("cuda", 0)
+    yt = torch.tensor(y, device=dev)
+    aty = torch.full((y.shape[0], 256), float("nan"), dtype=torch.float64, device=dev)
+    plan.aty_device(y.shape[0], yt, aty, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    plan.close()
+    got = aty.cpu().numpy()
+    ref = y @ basis
+    np.testing.assert_allclose(got[:, :250], ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+    assert (got[:, 250:] == 0).all()
+
+
 def test_full_size_kkt_c4(gpu):
     """BASELINE.json configs[3] at full size: the result of every voxel satisfies the NNLS optimality (KKT)
     conditions  x >= 0,  w = A^T(y_ext - A x) <= tol on x == 0,  |w| <= tol on x > 0 -- size independent and
