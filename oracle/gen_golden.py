@@ -221,5 +221,38 @@ def main():
     gen_nnls("g4_nnls_250_r2_maxiter20", (0.0008, 0.5), 250, 2, 0.02, 32, 32, rng, max_iter=20)
 
 
+def main_g7():
+    """Second batch (own generator, so the first batch stays byte-identical): free T1 / STEAM factors through the
+    reference's default FD Jacobian, and infinite bounds (Coleman-Li scaling with v = 1 on unbounded sides)."""
+    from pyneapple import BiExpModel, MonoExpModel
+
+    rng = np.random.default_rng(SEED + 7)
+    mono_p0 = {"S0": 1000.0, "D": 1e-3}
+    mono_bd = {"S0": (1.0, 5000.0), "D": (1e-5, 0.1)}
+    mono_tr = {"S0": (500, 1500), "D": (5e-4, 3e-3)}
+    gen_curvefit("g7_mono_t1_free", MonoExpModel(fit_t1=True, repetition_time=3000.0), ["S0", "D", "T1"],
+                 dict(mono_tr, T1=(800, 1600)), dict(mono_p0, T1=1000.0), dict(mono_bd, T1=(100.0, 5000.0)),
+                 16, 96, [0.0, 0.01], rng)
+    bi_p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001}
+    bi_bd = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}
+    bi_tr = {"f1": (0.1, 0.4), "D1": (5e-3, 5e-2), "D2": (5e-4, 2e-3)}
+    gen_curvefit("g7_bi_s0_steam_free", BiExpModel(fit_s0=True, fit_t1=True, fit_t1_steam=True, repetition_time=2500.0, mixing_time=30.0),
+                 ["f1", "D1", "D2", "S0", "T1"], dict(bi_tr, S0=(500, 1500), T1=(800, 1600)),
+                 dict(bi_p0, S0=1000.0, T1=1000.0), dict(bi_bd, S0=(1.0, 5000.0), T1=(100.0, 5000.0)), 24, 96, [0.0, 0.01], rng)
+    inf = float("inf")
+    gen_curvefit("g7_mono_inf_bounds", MonoExpModel(), ["S0", "D"], mono_tr, mono_p0, {"S0": (0.0, inf), "D": (-inf, inf)},
+                 16, 96, [0.0, 0.01], rng, bvalues=np.linspace(0, 1200, 16))
+    gen_curvefit("g7_bi_half_inf_bounds", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0,
+                 {"f1": (-inf, inf), "D1": (1e-3, inf), "D2": (-inf, 5e-3)}, 24, 128, [0.0, 0.01, 0.05], rng)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        main_g7()
+    else:
+        main()
+        main_g7()

@@ -28,6 +28,55 @@ CURVEFIT_FIXTURES = {
     "g3_tri_s0": "tri_s0", "g3_tri_full": "tri_full",
     "g5_bi_pervoxel": "bi_reduced", "g5_tri_pervoxel": "tri_reduced",
 }
+# second batch (oracle/gen_golden.py main_g7): (kernel model, extra solver arguments, index of the amplitude that is
+# degenerate with T1 or None).  With a free T1 only amplitude * relaxation factor is identifiable (a flat valley:
+# SciPy's own answer along it depends on rounding), so parity is asserted on that product, on the other parameters
+# and on the cost.  With infinite bounds a fast compartment's D can run away (exp(-b D) = 0 for every b > 0): those
+# voxels are compared on the cost.
+G7_FIXTURES = {
+    "g7_mono_t1_free": ("mono", dict(t1_mode=1, tr=3000.0), 0),
+    "g7_bi_s0_steam_free": ("bi_s0", dict(t1_mode=2, tr=2500.0, tm=30.0), 3),
+    "g7_mono_inf_bounds": ("mono", {}, None),
+    "g7_bi_half_inf_bounds": ("bi_reduced", {}, None),
+}
+
+
+def check_g7(r, d, kw, amp):
+    """Shared assertions of the g7 fixtures for the oracle and the HIP path (r: result dict, popt (n, n_vox))."""
+    assert ((r["status"] > 0) == d["success"]).all()
+    got, ref = r["popt"].T, d["popt"]
+    if amp is not None:
+        tr, tm, steam = kw["tr"], kw.get("tm", 0.0), kw["t1_mode"] == 2
+        fac = lambda T1: (1 - np.exp(-tr / T1)) * (np.exp(-tm / T1) if steam else 1.0)
+        prod_g, prod_r = got[:, amp] * fac(got[:, -1]), ref[:, amp] * fac(ref[:, -1])
+        assert np.abs(prod_g / prod_r - 1).max() < 1e-5
+        others = [k for k in range(ref.shape[1]) if k not in (amp, ref.shape[1] - 1)]
+        assert rel_err(got[:, others], ref[:, others]).max() <= 1e-4
+    else:
+        # a compartment whose D ran away under an infinite upper bound (exp(-b_1 D) < 1e-3: it only contributes at
+        # b = 0) leaves that D undetermined -- SciPy's own answer there depends on rounding; cost only for those
+        b1 = np.sort(d["bvalues"])[1]
+        dcols = [k for k, nm in enumerate(d["all_param_names"]) if str(nm).startswith("D")]
+        well = (np.exp(-b1 * ref[:, dcols]) >= 1e-3).all(axis=1)
+        assert well.mean() > 0.9
+        assert rel_err(got[well], ref[well]).max() <= 1e-4
+    # every voxel ends at an equally good minimum: cost of the reference's popt, re-evaluated with the stand-in models
+    from pyneapple_amd import models as M
+
+    name = str(d["all_param_names"][-1])
+    n_all = len(d["all_param_names"])
+    t1kw = {}
+    if amp is not None:
+        t1kw = dict(fit_t1=True, repetition_time=kw["tr"])
+        if kw["t1_mode"] == 2:
+            t1kw.update(fit_t1_steam=True, mixing_time=kw["tm"])
+    n_base = n_all - (1 if amp is not None else 0)
+    model = {2: M.MonoExpModel(**t1kw), 3: M.BiExpModel(**t1kw), 4: M.BiExpModel(fit_s0=True, **t1kw)}[n_base]
+    cost_ref = np.array([0.5 * np.sum((model.forward(d["bvalues"], *ref[i]) - d["y"][i]) ** 2) for i in range(len(ref))])
+    scale = 0.5 * np.sum(d["y"] ** 2, axis=1)  # noise-free voxels end at cost ~ 1e-26: compare against the signal energy
+    assert (np.abs(r["cost"] - cost_ref) <= 1e-6 * cost_ref + 1e-12 * scale).all()
+
+
 NNLS_FIXTURES = ["g4_nnls_250_r2", "g4_nnls_250_r1", "g4_nnls_250_r3", "g4_nnls_50_r2", "g4_nnls_50_r0",
                  "g4_nnls_250_r2_maxiter20"]
 

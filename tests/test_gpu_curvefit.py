@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import CURVEFIT_FIXTURES, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
+from conftest import CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -31,6 +31,16 @@ def test_fd_matches_reference_golden(gpu, name):
         if good.any():
             e = pcov_norm_err(r["pcov"][sel][good], d["pcov"][sel][good])
             assert np.median(e) < 1e-5 and (e < 1e-2).mean() > 0.97
+
+
+@pytest.mark.parametrize("name", sorted(G7_FIXTURES))
+def test_fd_matches_reference_golden_g7(gpu, name):
+    """Reference fixtures with a free T1 / STEAM factor and with infinite bounds (conftest.G7_FIXTURES)."""
+    model, kw, amp = G7_FIXTURES[name]
+    d = load_golden(name)
+    r = gpu.curvefit(model, d["bvalues"], d["y"], d["p0_vals"], d["lo_vals"], d["hi_vals"], max_nfev=int(d["max_iter"]),
+                     ftol=float(d["tol"]), jac="fd", **kw)
+    check_g7(r, d, kw, amp)
 
 
 @pytest.mark.parametrize("model,n_b,n_vox", [("mono", 16, 1024), ("bi_reduced", 24, 20000), ("tri_reduced", 32, 20000),

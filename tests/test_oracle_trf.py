@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import CURVEFIT_FIXTURES, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
+from conftest import CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
 
 RTOL = 1e-4  # BASELINE.json north_star: rtol=1e-4 (fp64) per parameter
 
@@ -30,6 +30,16 @@ def test_oracle_matches_reference_golden(oracle, name):
         if good.any():
             assert np.median(pcov_norm_err(r["pcov"][sel][good], d["pcov"][sel][good])) < 1e-5
             assert (pcov_norm_err(r["pcov"][sel][good], d["pcov"][sel][good]) < 1e-2).mean() > 0.97
+
+
+@pytest.mark.parametrize("name", sorted(G7_FIXTURES))
+def test_oracle_matches_reference_golden_g7(oracle, name):
+    """Free T1 / STEAM factor (FD Jacobian) and infinite bounds; see conftest.G7_FIXTURES for what is compared."""
+    model, kw, amp = G7_FIXTURES[name]
+    d = load_golden(name)
+    r = oracle.curvefit(model, d["bvalues"], d["y"], d["p0_vals"], d["lo_vals"], d["hi_vals"], max_nfev=int(d["max_iter"]),
+                        ftol=float(d["tol"]), jac="fd", **kw)
+    check_g7(r, d, kw, amp)
 
 
 def test_oracle_fixed_params_golden(oracle):
