@@ -246,6 +246,23 @@ def main_g7():
                  {"f1": (-inf, inf), "D1": (1e-3, inf), "D2": (-inf, 5e-3)}, 24, 128, [0.0, 0.01, 0.05], rng)
 
 
+def main_g8():
+    """Third batch: two per-pixel fixed parameters (SegmentedFitter with two maps from step 1; analytic Jacobian)."""
+    from pyneapple import MonoExpModel, TriExpModel
+
+    rng = np.random.default_rng(SEED + 8)
+    tri_p0 = {"f1": 0.2, "D1": 0.05, "f2": 0.3, "D2": 0.005, "D3": 0.001}
+    tri_bd = {"f1": (0.0, 1.0), "D1": (0.01, 0.5), "f2": (0.0, 1.0), "D2": (2e-3, 0.01), "D3": (1e-5, 2e-3)}
+    tri_tr = {"f1": (0.1, 0.3), "D1": (0.03, 0.1), "f2": (0.2, 0.4), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)}
+    gen_curvefit("g8_tri_fixed_D2_D3", TriExpModel(), ["f1", "D1", "f2", "D2", "D3"], tri_tr, tri_p0, tri_bd, 32, 96,
+                 [0.0, 0.01], rng, fixed={"D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)})
+    mono_p0 = {"S0": 1000.0, "D": 1e-3, "T1": 1000.0}
+    mono_bd = {"S0": (1.0, 5000.0), "D": (1e-5, 0.1), "T1": (100.0, 5000.0)}
+    mono_tr = {"S0": (500, 1500), "D": (5e-4, 3e-3), "T1": (800, 1600)}
+    gen_curvefit("g8_mono_t1_fixed_S0_T1", MonoExpModel(fit_t1=True, repetition_time=3000.0), ["S0", "D", "T1"], mono_tr,
+                 mono_p0, mono_bd, 16, 64, [0.0, 0.01], rng, fixed={"S0": (500, 1500), "T1": (800, 1600)})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
@@ -253,6 +270,13 @@ if __name__ == "__main__":
         sys.path.insert(0, REF_SRC)
         _install_shims()
         main_g7()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g8":
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        main_g8()
     else:
         main()
         main_g7()
+        main_g8()

@@ -56,7 +56,7 @@ template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const Curvefi
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }
 
-// Built per model: all parameters free (FD or analytic Jacobian) and exactly one fixed parameter (analytic, like the
+// Built per model: all parameters free (FD or analytic Jacobian) and one or two fixed parameters (analytic, like the
 // reference: curvefit.py:274-288), each without and with the T1 / STEAM factor.
 template <int MODEL, bool T1> static int launch_t1(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
     constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
@@ -67,8 +67,11 @@ template <int MODEL, bool T1> static int launch_t1(int n_free, int jac_mode, con
     if constexpr (NP >= 2) {
         if (n_free == NP - 1) return launch_pv<MODEL, NP - 1, false, T1>(args, cus, st);
     }
-    return set_error(PNX_ERR_UNSUPPORTED, "model %d%s with %d free parameters is not built (built: %d and %d)", MODEL,
-                     T1 ? "+T1" : "", n_free, NP, NP - 1);
+    if constexpr (NP >= 3) {
+        if (n_free == NP - 2) return launch_pv<MODEL, NP - 2, false, T1>(args, cus, st);
+    }
+    return set_error(PNX_ERR_UNSUPPORTED, "model %d%s with %d free parameters is not built (built: %d, %d and %d: at most two "
+                     "fixed parameters)", MODEL, T1 ? "+T1" : "", n_free, NP, NP - 1, NP - 2);
 }
 
 template <int MODEL> static int launch_model(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {

@@ -226,6 +226,24 @@ def test_sweep_kernel_matches_numpy(gpu, model, n_b):
         assert (np.abs(h.cpu().numpy() - h_ref) / hs).max() < tol * 10
 
 
+def test_two_fixed_parameters_match_reference_golden(gpu):
+    """Two per-pixel fixed maps: tri reduced with D2, D3 fixed (N = 3 of 5) and mono + T1 with S0, T1 fixed (N = 1)."""
+    from test_oracle_trf import _two_fixed_cases
+
+    for d, model, free, fixed_idx, fv, kw in _two_fixed_cases():
+        r = gpu.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                         fixed_idx=fixed_idx, fixed_vals=fv, jac="analytic", **kw)
+        assert (r["status"] > 0).all() and d["success"].all()
+        assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-8
+        e = pcov_norm_err(r["pcov"][d["sigma"] > 0], d["pcov"][d["sigma"] > 0])
+        assert np.median(e) < 1e-6
+    # three fixed parameters are not built: loud error, no fallback
+    d = load_golden("g8_tri_fixed_D2_D3")
+    with pytest.raises(Exception, match="not built"):
+        gpu.curvefit("tri_reduced", d["bvalues"], d["y"], d["p0_vals"][[0, 1]], d["lo_vals"][[0, 1]], d["hi_vals"][[0, 1]],
+                     fixed_idx=[2, 3, 4], fixed_vals=np.array([0.3, 0.005, 0.001]), jac="analytic")
+
+
 def test_t1_fixed_matches_reference_golden(gpu):
     """MonoExp + T1 factor with a per-pixel fixed T1 map (reference fixture g6_mono_t1_fixed)."""
     d = load_golden("g6_mono_t1_fixed")

@@ -54,6 +54,22 @@ def test_oracle_fixed_params_golden(oracle):
     assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-9
 
 
+def _two_fixed_cases():
+    d = load_golden("g8_tri_fixed_D2_D3")
+    yield d, "tri_reduced", [0, 1, 2], [3, 4], np.stack([d["fixed_D2"], d["fixed_D3"]]), {}
+    d = load_golden("g8_mono_t1_fixed_S0_T1")
+    yield d, "mono", [1], [0, 2], np.stack([d["fixed_S0"], d["fixed_T1"]]), dict(t1_mode=1, tr=3000.0)
+
+
+def test_oracle_two_fixed_params_golden(oracle):
+    """Two per-pixel fixed maps (SegmentedFitter with two parameters carried over from step 1)."""
+    for d, model, free, fixed_idx, fv, kw in _two_fixed_cases():
+        r = oracle.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                            fixed_idx=fixed_idx, fixed_vals=fv, jac="analytic", **kw)
+        assert (r["status"] > 0).all() and d["success"].all()
+        assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-9
+
+
 def _scipy_fit(fun, b, y, p0, lo, hi, max_nfev=250, tol=1e-8):
     from scipy.optimize import curve_fit
 
