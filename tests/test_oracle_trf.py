@@ -94,6 +94,34 @@ def test_oracle_matches_scipy_fresh_data(oracle):
     assert (rel_err(r["popt"].T, ref).max(axis=1) <= RTOL).mean() >= 0.97
 
 
+def _p0_on_bounds_case():
+    """biexp, clinical (non-uniform) b-values, start values sitting exactly on a lower and on an upper bound:
+    least_squares moves them strictly inside first (least_squares.py:827-828, rstep = 1e-10)."""
+    rng = np.random.default_rng(11)
+    b = np.array([0, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 400, 600, 800], float)
+    n = 40
+    f1, D1, D2 = rng.uniform(0.1, 0.4, n), rng.uniform(5e-3, 5e-2, n), rng.uniform(5e-4, 2e-3, n)
+    y = (f1[:, None] * np.exp(-b * D1[:, None]) + (1 - f1[:, None]) * np.exp(-b * D2[:, None]))
+    y *= 1 + 0.01 * rng.standard_normal(y.shape)
+    p0 = np.array([0.0, 0.1, 0.001])   # f1 on its lower bound, D1 on its upper bound
+    lo = np.array([0.0, 1e-3, 1e-5])
+    hi = np.array([1.0, 0.1, 5e-3])
+    return b, y, p0, lo, hi
+
+
+def test_oracle_matches_scipy_p0_on_bounds(oracle):
+    b, y, p0, lo, hi = _p0_on_bounds_case()
+
+    def bi(x, f1, D1, D2):
+        return f1 * np.exp(-x * D1) + (1 - f1) * np.exp(-x * D2)
+
+    r = oracle.curvefit("bi_reduced", b, y, p0, lo, hi)
+    fits = [_scipy_fit(bi, b, y[i], p0, lo, hi) for i in range(len(y))]
+    ref = np.array([f[0] for f in fits])
+    assert ((r["status"] > 0) == np.array([f[1] for f in fits])).all()
+    assert (rel_err(r["popt"].T, ref).max(axis=1) <= RTOL).mean() >= 0.97
+
+
 def test_oracle_failure_sentinels(oracle):
     from pyneapple_amd import synth
 
