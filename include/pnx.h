@@ -125,6 +125,16 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const d
                            int mem, int device, void *stream);
 
 /*
+ * The same fit with fp32 STORAGE: b, y, p0 / lo / hi, fixed in and popt, pcov, cost out are float; the arithmetic is
+ * the fp64 of pnx_curvefit_batch_f64 (values are widened on the device, results narrowed there).  This is what the
+ * reference computes for a float32 image -- curve_fit casts ydata to float64 (scipy:_minpack_py.py:930) -- without
+ * the host-side float64 copy and with half the PCIe traffic.  SURVEY.md 8b: "T in {f32, f64} via suffix".
+ */
+int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const float *b, const float *y, const float *p0,
+                           const float *lo, const float *hi, const float *fixed, float *popt, float *pcov,
+                           int8_t *status, int32_t *nfev, float *cost, int mem, int device, void *stream);
+
+/*
  * NNLS plan: everything that is shared by all voxels of one fit -- the regularised design matrix
  * A = [basis; reg] (nnls_solver.py:61-73) -- is uploaded and factored into its Gram form once.
  *   basis (n_meas, n_bins) row-major host;  reg (n_reg, n_bins) row-major host or NULL (n_reg = 0).
@@ -143,6 +153,9 @@ int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
  */
 int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
                        double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
+/* fp32 storage of y, coeff and rnorm, fp64 arithmetic (halves the 8.4 GB coefficient volume of the C4 workload). */
+int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int max_iter, float *coeff, float *rnorm,
+                       int8_t *status, int32_t *iters, int mem, void *stream);
 
 /*
  * The MFMA Gram step of the NNLS path on its own: aty (n_vox, 256) = y (n_vox, n_meas) . basis (n_meas, n_bins),

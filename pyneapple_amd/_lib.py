@@ -20,6 +20,7 @@ JAC_FD, JAC_ANALYTIC = 0, 1
 # every symbol include/pnx.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "pnx_version", "pnx_device_count", "pnx_last_error", "pnx_model_n_params", "pnx_curvefit_batch_f64",
+    "pnx_curvefit_batch_f32", "pnx_nnls_solve_f32",
     "pnx_nnls_plan_create", "pnx_nnls_plan_destroy", "pnx_nnls_solve_f64", "pnx_nnls_aty_f64", "pnx_nnls_batch_f64",
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
 ]
@@ -95,12 +96,16 @@ def load():
     lib.pnx_curvefit_batch_f64.restype = C.c_int
     lib.pnx_curvefit_batch_f64.argtypes = [C.POINTER(CurvefitOpts), C.c_int64, dp, dp, dp, dp, dp, dp, dp, dp, vp, vp,
                                            dp, C.c_int, C.c_int, vp]
+    lib.pnx_curvefit_batch_f32.restype = C.c_int
+    lib.pnx_curvefit_batch_f32.argtypes = lib.pnx_curvefit_batch_f64.argtypes  # all data pointers are void*
     lib.pnx_nnls_plan_create.restype = C.c_int
     lib.pnx_nnls_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, dp, dp, C.c_int, C.c_int]
     lib.pnx_nnls_plan_destroy.restype = C.c_int
     lib.pnx_nnls_plan_destroy.argtypes = [vp]
     lib.pnx_nnls_solve_f64.restype = C.c_int
     lib.pnx_nnls_solve_f64.argtypes = [vp, C.c_int64, dp, C.c_int, dp, dp, vp, vp, C.c_int, vp]
+    lib.pnx_nnls_solve_f32.restype = C.c_int
+    lib.pnx_nnls_solve_f32.argtypes = lib.pnx_nnls_solve_f64.argtypes
     lib.pnx_nnls_aty_f64.restype = C.c_int
     lib.pnx_nnls_aty_f64.argtypes = [vp, C.c_int64, vp, vp, vp]
     lib.pnx_nnls_batch_f64.restype = C.c_int

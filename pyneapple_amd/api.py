@@ -51,22 +51,25 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
              gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0):
     """Batched bounded NLLS on host (numpy) arrays.  Shapes as in include/pnx.h.
 
+    A float32 signal array selects the fp32-storage entry point (pnx_curvefit_batch_f32: every data array float32 in
+    and out, fp64 arithmetic on the device); anything else goes through pnx_curvefit_batch_f64.
     Returns dict(popt (n_free, n_vox), pcov (n_vox, n_free, n_free) | None, status int8, nfev int32, cost).
     """
     _lib.require_device()
-    b = np.ascontiguousarray(b, np.float64)
-    y = np.ascontiguousarray(np.atleast_2d(y), np.float64)
+    dt = np.float32 if getattr(y, "dtype", None) == np.float32 else np.float64
+    b = np.ascontiguousarray(b, dt)
+    y = np.ascontiguousarray(np.atleast_2d(y), dt)
     n_vox, n_b = y.shape
     if b.shape != (n_b,):
         raise ValueError(f"b has shape {b.shape}, expected ({n_b},)")
-    p0 = np.ascontiguousarray(p0, np.float64)
-    lo = np.ascontiguousarray(lo, np.float64)
-    hi = np.ascontiguousarray(hi, np.float64)
+    p0 = np.ascontiguousarray(p0, dt)
+    lo = np.ascontiguousarray(lo, dt)
+    hi = np.ascontiguousarray(hi, dt)
     per_voxel = p0.ndim == 2
     fv = None
     fpv = False
     if len(fixed_idx):
-        fv = np.ascontiguousarray(fixed_vals, np.float64)
+        fv = np.ascontiguousarray(fixed_vals, dt)
         fpv = fv.ndim == 2
     o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac, t1_mode, tr, tm)
     n = o.n_free
@@ -75,21 +78,28 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
         raise ValueError(f"p0/lo/hi must have shape {want}")
     if fv is not None and fv.shape != ((o.n_fixed, n_vox) if fpv else (o.n_fixed,)):
         raise ValueError("fixed_vals has the wrong shape")
-    popt = np.empty((n, n_vox))
-    pcov = np.empty((n_vox, n, n)) if want_pcov else None
+    popt = np.empty((n, n_vox), dt)
+    pcov = np.empty((n_vox, n, n), dt) if want_pcov else None
     status = np.empty(n_vox, np.int8)
     nfev = np.empty(n_vox, np.int32)
-    cost = np.empty(n_vox)
-    check(load().pnx_curvefit_batch_f64(C.byref(o), n_vox, ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi), ptr(fv),
-                                        ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost), MEM_HOST, device,
-                                        None))
+    cost = np.empty(n_vox, dt)
+    fn = load().pnx_curvefit_batch_f32 if dt is np.float32 else load().pnx_curvefit_batch_f64
+    check(fn(C.byref(o), n_vox, ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi), ptr(fv),
+                                        ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost), MEM_HOST, device, None))
     return dict(popt=popt, pcov=pcov, status=status, nfev=nfev, cost=cost)
 
 
 def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, device, stream=None):
-    """Enqueue a batched fit on HBM-resident torch tensors (asynchronous; caller synchronises)."""
-    b = np.ascontiguousarray(b, np.float64)
-    check(load().pnx_curvefit_batch_f64(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
+    """Enqueue a batched fit on HBM-resident torch tensors (asynchronous; caller synchronises).  float32 tensors
+    select the fp32-storage entry point."""
+    f32 = "float32" in str(getattr(y, "dtype", ""))
+    b = np.ascontiguousarray(b, np.float32 if f32 else np.float64)
+    if not getattr(opts, "per_voxel_p0_bounds", 0):
+        p0, lo, hi = (np.ascontiguousarray(a, b.dtype) for a in (p0, lo, hi))
+    if isinstance(fixed, np.ndarray):
+        fixed = np.ascontiguousarray(fixed, b.dtype)
+    fn = load().pnx_curvefit_batch_f32 if f32 else load().pnx_curvefit_batch_f64
+    check(fn(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
                                         ptr(fixed), ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost),
                                         MEM_DEVICE, int(device), stream))
 
@@ -115,20 +125,23 @@ class NnlsPlan:
                                           device))
 
     def solve(self, y, max_iter=250):
-        y = np.ascontiguousarray(np.atleast_2d(y), np.float64)
+        dt = np.float32 if getattr(y, "dtype", None) == np.float32 else np.float64  # float32 in -> float32 out
+        y = np.ascontiguousarray(np.atleast_2d(y), dt)
         n_vox = y.shape[0]
         if y.shape[1] != self.n_meas:
             raise ValueError(f"signal has {y.shape[1]} measurements, basis has {self.n_meas}")
-        coeff = np.empty((n_vox, self.n_bins))
-        rnorm = np.empty(n_vox)
+        coeff = np.empty((n_vox, self.n_bins), dt)
+        rnorm = np.empty(n_vox, dt)
         status = np.empty(n_vox, np.int8)
         iters = np.empty(n_vox, np.int32)
-        check(load().pnx_nnls_solve_f64(self._h, n_vox, ptr(y), int(max_iter), ptr(coeff), ptr(rnorm), ptr(status),
+        fn = load().pnx_nnls_solve_f32 if dt is np.float32 else load().pnx_nnls_solve_f64
+        check(fn(self._h, n_vox, ptr(y), int(max_iter), ptr(coeff), ptr(rnorm), ptr(status),
                                         ptr(iters), MEM_HOST, None))
         return dict(coefficients=coeff, residual=rnorm, status=status, iters=iters)
 
     def solve_device(self, n_vox, y, max_iter, coeff, rnorm, status, iters, stream=None):
-        check(load().pnx_nnls_solve_f64(self._h, int(n_vox), ptr(y), int(max_iter), ptr(coeff), ptr(rnorm),
+        fn = load().pnx_nnls_solve_f32 if "float32" in str(getattr(y, "dtype", "")) else load().pnx_nnls_solve_f64
+        check(fn(self._h, int(n_vox), ptr(y), int(max_iter), ptr(coeff), ptr(rnorm),
                                         ptr(status), ptr(iters), MEM_DEVICE, stream))
 
     def aty_device(self, n_vox, y, aty=None, stream=None):

@@ -408,10 +408,44 @@ int pnx_model_n_params(int model) {
     return n < 0 ? set_error(PNX_ERR_INVALID, "unknown model %d", model) : n;
 }
 
-int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y,
-                           const double *p0, const double *lo, const double *hi, const double *fixed, double *popt,
-                           double *pcov, int8_t *status, int32_t *nfev, double *cost, int mem, int device,
-                           void *stream) {
+}  // extern "C"
+
+// element-wise conversion between the storage type of an _f32 entry point and the fp64 the kernels compute in
+template <typename S, typename D> __global__ void cvt_kernel(const S *__restrict__ src, D *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (D)src[i];
+}
+template <typename S, typename D> static int cvt(const S *src, D *dst, size_t n, hipStream_t st) {
+    if (!n) return PNX_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((cvt_kernel<S, D>), dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+    PNX_HIP(hipGetLastError());
+    return PNX_OK;
+}
+
+// stream-ordered scratch for the device-pointer _f32 path
+struct AsyncBuf {
+    void *p = nullptr;
+    hipStream_t st = nullptr;
+    int alloc(size_t bytes, hipStream_t s) {
+        st = s;
+        hipError_t e = hipMallocAsync(&p, bytes ? bytes : 8, s);
+        if (e != hipSuccess) return set_error(PNX_ERR_NOMEM, "hipMallocAsync(%zu): %s", bytes, hipGetErrorString(e));
+        return PNX_OK;
+    }
+    ~AsyncBuf() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+};
+
+// T = double: the fp64 entry point.  T = float: fp32 STORAGE (signal, p0 / bounds / fixed maps in, popt / pcov / cost
+// out) with the same fp64 arithmetic -- what the reference does with a float32 image (curve_fit casts ydata to float64).
+template <typename T>
+static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b, const T *y, const T *p0, const T *lo,
+                          const T *hi, const T *fixed, T *popt, T *pcov, int8_t *status, int32_t *nfev, T *cost, int mem,
+                          int device, void *stream) {
+    constexpr bool F32 = sizeof(T) == 4;
     int rc = check_curvefit_opts(o);
     if (rc) return rc;
     if (n_vox < 0) return set_error(PNX_ERR_INVALID, "n_vox < 0");
@@ -424,26 +458,68 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     if (rc) return rc;
     PNX_HIP(hipSetDevice(device));
     const int n = o->n_free;
+    const size_t nv = (size_t)n_vox;
+    const bool pv = o->per_voxel_p0_bounds != 0, fpv = o->n_fixed && o->fixed_per_voxel;
+    // the small shared host arrays (b-values, shared p0 / bounds / fixed values) as fp64
+    double bd[PNX_MAX_BVALUES], p0d[PNX_MAX_PARAMS], lod[PNX_MAX_PARAMS], hid[PNX_MAX_PARAMS], fxd[PNX_MAX_PARAMS];
+    for (int i = 0; i < o->n_b; ++i) bd[i] = (double)b[i];
+    if (!pv)
+        for (int k = 0; k < n; ++k) {
+            p0d[k] = (double)p0[k];
+            lod[k] = (double)lo[k];
+            hid[k] = (double)hi[k];
+        }
+    if (o->n_fixed && !fpv)
+        for (int k = 0; k < o->n_fixed; ++k) fxd[k] = (double)fixed[k];
+    auto as_d = [](const T *p) { return reinterpret_cast<const double *>(p); };  // only used when T is double
+
     if (mem == PNX_MEM_DEVICE) {
         if (pcov && (!status || !cost))
             return set_error(PNX_ERR_INVALID, "device mode: pcov needs the status and cost outputs too (the covariance "
                                               "epilogue kernel reads them)");
+        hipStream_t st = (hipStream_t)stream;
+        if constexpr (!F32) {
+            return curvefit_device(o, n_vox, bd, as_d(y), pv ? as_d(p0) : p0d, pv ? as_d(lo) : lod, pv ? as_d(hi) : hid,
+                                   fpv ? as_d(fixed) : fxd, (double *)popt, (double *)pcov, status, nfev, (double *)cost, dev, st);
+        } else {
+            AsyncBuf y64, p64, l64, h64, f64, o64, c64, k64;
+            if ((rc = y64.alloc(nv * o->n_b * 8, st)) || (rc = cvt(y, (double *)y64.p, nv * o->n_b, st))) return rc;
+            if (pv) {
+                if ((rc = p64.alloc(nv * n * 8, st)) || (rc = l64.alloc(nv * n * 8, st)) || (rc = h64.alloc(nv * n * 8, st))) return rc;
+                if ((rc = cvt(p0, (double *)p64.p, nv * n, st)) || (rc = cvt(lo, (double *)l64.p, nv * n, st)) ||
+                    (rc = cvt(hi, (double *)h64.p, nv * n, st)))
+                    return rc;
+            }
+            if (fpv && ((rc = f64.alloc(nv * o->n_fixed * 8, st)) || (rc = cvt(fixed, (double *)f64.p, nv * o->n_fixed, st)))) return rc;
+            if ((rc = o64.alloc(nv * n * 8, st))) return rc;
+            if (pcov && (rc = c64.alloc(nv * n * n * 8, st))) return rc;
+            if ((cost || pcov) && (rc = k64.alloc(nv * 8, st))) return rc;
+            rc = curvefit_device(o, n_vox, bd, (const double *)y64.p, pv ? (const double *)p64.p : p0d,
+                                 pv ? (const double *)l64.p : lod, pv ? (const double *)h64.p : hid,
+                                 fpv ? (const double *)f64.p : fxd, (double *)o64.p, pcov ? (double *)c64.p : nullptr, status,
+                                 nfev, (double *)k64.p, dev, st);
+            if (rc) return rc;
+            if ((rc = cvt((const double *)o64.p, popt, nv * n, st))) return rc;
+            if (pcov && (rc = cvt((const double *)c64.p, pcov, nv * n * n, st))) return rc;
+            if (cost && (rc = cvt((const double *)k64.p, cost, nv, st))) return rc;
+            return PNX_OK;  // AsyncBuf destructors enqueue the frees behind the conversions
+        }
     }
-    if (mem == PNX_MEM_DEVICE)
-        return curvefit_device(o, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, dev, (hipStream_t)stream);
 
     // ---- host staging: chunk ring (run_pipeline above)
-    const size_t nv = (size_t)n_vox;
     const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", 3 << 18, 1024, 1 << 26);
     const int n_chunks = (int)((nv + chunk - 1) / chunk);
     const int n_slots = n_chunks < 3 ? n_chunks : env_int("PNX_HOST_SLOTS", 3, 2, 8);
     const size_t cap = nv < chunk ? nv : chunk;
-    const bool pv = o->per_voxel_p0_bounds != 0, fpv = o->n_fixed && o->fixed_per_voxel;
     const bool need_stat = status || pcov, need_cost = cost || pcov;
     struct Slot {
         DevBuf slab;
+        // fp64 working set of the kernels ...
         double *y = nullptr, *p0 = nullptr, *lo = nullptr, *hi = nullptr, *fx = nullptr, *popt = nullptr, *pcov = nullptr,
                *cost = nullptr;
+        // ... and the T-typed transfer buffers (the same memory when T is double)
+        T *ty = nullptr, *tp0 = nullptr, *tlo = nullptr, *thi = nullptr, *tfx = nullptr, *tpopt = nullptr, *tpcov = nullptr,
+          *tcost = nullptr;
         int8_t *stat = nullptr;
         int32_t *nfev = nullptr;
     };
@@ -453,18 +529,22 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
         for (int pass = 0; pass < 2; ++pass) {  // pass 0 sizes the slab, pass 1 carves it
             Carver c;
             c.base = (char *)S.slab.p;
-            S.y = (double *)c.take(cap * o->n_b * sizeof(double));
+            auto both = [&](double *&d64, T *&t, size_t count) {
+                d64 = (double *)c.take(count * sizeof(double));
+                t = F32 ? (T *)c.take(count * sizeof(T)) : (T *)d64;
+            };
+            both(S.y, S.ty, cap * o->n_b);
             if (pv) {
-                S.p0 = (double *)c.take(cap * n * sizeof(double));
-                S.lo = (double *)c.take(cap * n * sizeof(double));
-                S.hi = (double *)c.take(cap * n * sizeof(double));
+                both(S.p0, S.tp0, cap * n);
+                both(S.lo, S.tlo, cap * n);
+                both(S.hi, S.thi, cap * n);
             }
-            if (fpv) S.fx = (double *)c.take(cap * o->n_fixed * sizeof(double));
-            S.popt = (double *)c.take(cap * n * sizeof(double));
-            if (pcov) S.pcov = (double *)c.take(cap * n * n * sizeof(double));
+            if (fpv) both(S.fx, S.tfx, cap * o->n_fixed);
+            both(S.popt, S.tpopt, cap * n);
+            if (pcov) both(S.pcov, S.tpcov, cap * n * n);
             if (need_stat) S.stat = (int8_t *)c.take(cap);
             if (nfev) S.nfev = (int32_t *)c.take(cap * sizeof(int32_t));
-            if (need_cost) S.cost = (double *)c.take(cap * sizeof(double));
+            if (need_cost) both(S.cost, S.tcost, cap);
             if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
         }
     }
@@ -477,48 +557,75 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const doub
         Slot &S = slots[slot];
         size_t v0, c;
         span(k, v0, c);
-        PNX_HIP(hipMemcpyAsync(S.y, y + v0 * o->n_b, c * o->n_b * sizeof(double), hipMemcpyHostToDevice, st));
+        PNX_HIP(hipMemcpyAsync(S.ty, y + v0 * o->n_b, c * o->n_b * sizeof(T), hipMemcpyHostToDevice, st));
         // parameter-major (k, n_vox) arrays: one row slice per parameter, device stride = c
         if (pv)
             for (int j = 0; j < n; ++j) {
-                PNX_HIP(hipMemcpyAsync(S.p0 + j * c, p0 + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
-                PNX_HIP(hipMemcpyAsync(S.lo + j * c, lo + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
-                PNX_HIP(hipMemcpyAsync(S.hi + j * c, hi + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.tp0 + j * c, p0 + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.tlo + j * c, lo + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.thi + j * c, hi + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, st));
             }
         if (fpv)
             for (int j = 0; j < o->n_fixed; ++j)
-                PNX_HIP(hipMemcpyAsync(S.fx + j * c, fixed + j * nv + v0, c * sizeof(double), hipMemcpyHostToDevice, st));
+                PNX_HIP(hipMemcpyAsync(S.tfx + j * c, fixed + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, st));
         return PNX_OK;
     };
     ops.launch = [&](int k, int slot, hipStream_t st) -> int {
         Slot &S = slots[slot];
         size_t v0, c;
         span(k, v0, c);
-        return curvefit_device(o, (int64_t)c, b, S.y, pv ? S.p0 : p0, pv ? S.lo : lo, pv ? S.hi : hi, fpv ? S.fx : fixed,
-                               S.popt, pcov ? S.pcov : nullptr, S.stat, S.nfev, S.cost, dev, st);
+        int r = PNX_OK;
+        if constexpr (F32) {
+            if ((r = cvt(S.ty, S.y, c * o->n_b, st))) return r;
+            if (pv && ((r = cvt(S.tp0, S.p0, c * n, st)) || (r = cvt(S.tlo, S.lo, c * n, st)) || (r = cvt(S.thi, S.hi, c * n, st)))) return r;
+            if (fpv && (r = cvt(S.tfx, S.fx, c * o->n_fixed, st))) return r;
+        }
+        r = curvefit_device(o, (int64_t)c, bd, S.y, pv ? S.p0 : p0d, pv ? S.lo : lod, pv ? S.hi : hid, fpv ? S.fx : fxd, S.popt,
+                            pcov ? S.pcov : nullptr, S.stat, S.nfev, S.cost, dev, st);
+        if (r) return r;
+        if constexpr (F32) {
+            if ((r = cvt(S.popt, S.tpopt, c * n, st))) return r;
+            if (pcov && (r = cvt(S.pcov, S.tpcov, c * n * n, st))) return r;
+            if (cost && (r = cvt(S.cost, S.tcost, c, st))) return r;
+        }
+        return PNX_OK;
     };
     ops.touch = [&](int k) {
         size_t v0, c;
         span(k, v0, c);
-        for (int j = 0; j < n; ++j) touch_pages(popt + j * nv + v0, c * sizeof(double));
-        if (pcov) touch_pages(pcov + v0 * n * n, c * n * n * sizeof(double));
+        for (int j = 0; j < n; ++j) touch_pages(popt + j * nv + v0, c * sizeof(T));
+        if (pcov) touch_pages(pcov + v0 * n * n, c * n * n * sizeof(T));
         if (status) touch_pages(status + v0, c);
         if (nfev) touch_pages(nfev + v0, c * sizeof(int32_t));
-        if (cost) touch_pages(cost + v0, c * sizeof(double));
+        if (cost) touch_pages(cost + v0, c * sizeof(T));
     };
     ops.d2h = [&](int k, int slot, hipStream_t st) -> int {
         Slot &S = slots[slot];
         size_t v0, c;
         span(k, v0, c);
         for (int j = 0; j < n; ++j)
-            PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, S.popt + j * c, c * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, S.pcov, c * n * n * sizeof(double), hipMemcpyDeviceToHost, st));
+            PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, S.tpopt + j * c, c * sizeof(T), hipMemcpyDeviceToHost, st));
+        if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, S.tpcov, c * n * n * sizeof(T), hipMemcpyDeviceToHost, st));
         if (status) PNX_HIP(hipMemcpyAsync(status + v0, S.stat, c, hipMemcpyDeviceToHost, st));
         if (nfev) PNX_HIP(hipMemcpyAsync(nfev + v0, S.nfev, c * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.cost, c * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.tcost, c * sizeof(T), hipMemcpyDeviceToHost, st));
         return PNX_OK;
     };
     return run_pipeline(n_chunks, n_slots, 2, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), device, (hipStream_t)stream, ops);
+}
+
+extern "C" {
+int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y,
+                           const double *p0, const double *lo, const double *hi, const double *fixed, double *popt,
+                           double *pcov, int8_t *status, int32_t *nfev, double *cost, int mem, int device,
+                           void *stream) {
+    return curvefit_batch<double>(o, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, mem, device, stream);
+}
+
+int pnx_curvefit_batch_f32(const pnx_curvefit_opts *o, int64_t n_vox, const float *b, const float *y, const float *p0,
+                           const float *lo, const float *hi, const float *fixed, float *popt, float *pcov, int8_t *status,
+                           int32_t *nfev, float *cost, int mem, int device, void *stream) {
+    return curvefit_batch<float>(o, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, mem, device, stream);
 }
 
 // ------------------------------------------------------------------------------------------- NNLS
@@ -555,8 +662,13 @@ int pnx_nnls_plan_destroy(pnx_nnls_plan *plan) {
     return PNX_OK;
 }
 
-int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
-                       double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream) {
+}  // extern "C"
+
+// T = double: fp64 entry point.  T = float: fp32 storage of the signal, the coefficients and rnorm; fp64 arithmetic.
+template <typename T>
+static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_iter, T *coeff, T *rnorm, int8_t *status,
+                      int32_t *iters, int mem, void *stream) {
+    constexpr bool F32 = sizeof(T) == 4;
     if (!plan) return set_error(PNX_ERR_INVALID, "plan is NULL");
     if (n_vox < 0 || (n_vox && (!y || !coeff || !rnorm))) return set_error(PNX_ERR_INVALID, "NULL data pointer");
     if (mem != PNX_MEM_HOST && mem != PNX_MEM_DEVICE) return set_error(PNX_ERR_INVALID, "mem=%d", mem);
@@ -565,33 +677,59 @@ int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int 
     PNX_HIP(hipSetDevice(P.device));
     hipStream_t st = (hipStream_t)stream;
     if (max_iter <= 0) max_iter = 3 * P.n_bins;  // scipy/optimize/_nnls.py:93-94
-    if (mem == PNX_MEM_DEVICE) return nnls_solve_device(&P, n_vox, y, max_iter, coeff, rnorm, status, iters, st);
+    const size_t nv = (size_t)n_vox;
+    int rc;
+    if (mem == PNX_MEM_DEVICE) {
+        if constexpr (!F32) {
+            return nnls_solve_device(&P, n_vox, (const double *)y, max_iter, (double *)coeff, (double *)rnorm, status, iters, st);
+        } else {
+            // converted in pieces of the kernel's own chunk so that the fp64 scratch stays at 2.4 GB
+            const size_t piece = (size_t)kAtyChunk < nv ? (size_t)kAtyChunk : nv;
+            AsyncBuf y64, c64, r64;
+            if ((rc = y64.alloc(piece * P.n_meas * 8, st)) || (rc = c64.alloc(piece * P.n_bins * 8, st)) || (rc = r64.alloc(piece * 8, st)))
+                return rc;
+            for (size_t off = 0; off < nv; off += piece) {
+                const size_t c = (nv - off) < piece ? (nv - off) : piece;
+                if ((rc = cvt(y + off * P.n_meas, (double *)y64.p, c * P.n_meas, st))) return rc;
+                rc = nnls_solve_device(&P, (int64_t)c, (const double *)y64.p, max_iter, (double *)c64.p, (double *)r64.p,
+                                       status ? status + off : nullptr, iters ? iters + off : nullptr, st);
+                if (rc) return rc;
+                if ((rc = cvt((const double *)c64.p, coeff + off * P.n_bins, c * P.n_bins, st)) ||
+                    (rc = cvt((const double *)r64.p, rnorm + off, c, st)))
+                    return rc;
+            }
+            return PNX_OK;
+        }
+    }
     // host staging: the same chunk ring as the curve fit, with ONE kernel stream -- the plan's device scratch (ATY
     // chunk, M overflow, queue) serves one solve at a time, and in-order launches on one stream guarantee that.
     // The (n_vox, n_bins) coefficient array is 8.4 GB for the C4 volume: its D2H and first-touch faults hide behind
     // the solves of the following chunks.
     std::lock_guard<std::mutex> plan_lock(plan->mu);
-    const size_t nv = (size_t)n_vox;
     const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 1 << 18, 1024, 1 << 22);
     const int n_chunks = (int)((nv + chunk - 1) / chunk);
     const int n_slots = n_chunks < 3 ? n_chunks : 3;
     const size_t cap = nv < chunk ? nv : chunk;
     struct Slot {
         DevBuf slab;
-        double *y = nullptr, *c = nullptr, *r = nullptr;
+        double *y = nullptr, *c = nullptr, *r = nullptr;  // fp64 working set
+        T *ty = nullptr, *tc = nullptr, *tr = nullptr;    // transfer buffers (same memory when T is double)
         int8_t *s = nullptr;
         int32_t *i = nullptr;
     };
     std::vector<Slot> slots(n_slots);
-    int rc;
     for (int w = 0; w < n_slots; ++w) {
         Slot &S = slots[w];
         for (int pass = 0; pass < 2; ++pass) {
             Carver c;
             c.base = (char *)S.slab.p;
-            S.y = (double *)c.take(cap * P.n_meas * sizeof(double));
-            S.c = (double *)c.take(cap * P.n_bins * sizeof(double));
-            S.r = (double *)c.take(cap * sizeof(double));
+            auto both = [&](double *&d64, T *&t, size_t count) {
+                d64 = (double *)c.take(count * sizeof(double));
+                t = F32 ? (T *)c.take(count * sizeof(T)) : (T *)d64;
+            };
+            both(S.y, S.ty, cap * P.n_meas);
+            both(S.c, S.tc, cap * P.n_bins);
+            both(S.r, S.tr, cap);
             S.s = (int8_t *)c.take(cap);
             S.i = (int32_t *)c.take(cap * sizeof(int32_t));
             if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
@@ -605,20 +743,27 @@ int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int 
     ops.h2d = [&](int k, int slot, hipStream_t s) -> int {
         size_t off, c;
         span(k, off, c);
-        PNX_HIP(hipMemcpyAsync(slots[slot].y, y + off * P.n_meas, c * P.n_meas * sizeof(double), hipMemcpyHostToDevice, s));
+        PNX_HIP(hipMemcpyAsync(slots[slot].ty, y + off * P.n_meas, c * P.n_meas * sizeof(T), hipMemcpyHostToDevice, s));
         return PNX_OK;
     };
     ops.launch = [&](int k, int slot, hipStream_t s) -> int {
         Slot &S = slots[slot];
         size_t off, c;
         span(k, off, c);
-        return nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
+        int r = PNX_OK;
+        if constexpr (F32)
+            if ((r = cvt(S.ty, S.y, c * P.n_meas, s))) return r;
+        r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
+        if (r) return r;
+        if constexpr (F32)
+            if ((r = cvt(S.c, S.tc, c * P.n_bins, s)) || (r = cvt(S.r, S.tr, c, s))) return r;
+        return PNX_OK;
     };
     ops.touch = [&](int k) {
         size_t off, c;
         span(k, off, c);
-        touch_pages(coeff + off * P.n_bins, c * P.n_bins * sizeof(double));
-        touch_pages(rnorm + off, c * sizeof(double));
+        touch_pages(coeff + off * P.n_bins, c * P.n_bins * sizeof(T));
+        touch_pages(rnorm + off, c * sizeof(T));
         if (status) touch_pages(status + off, c);
         if (iters) touch_pages(iters + off, c * sizeof(int32_t));
     };
@@ -626,13 +771,24 @@ int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int 
         Slot &S = slots[slot];
         size_t off, c;
         span(k, off, c);
-        PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, S.c, c * P.n_bins * sizeof(double), hipMemcpyDeviceToHost, s));
-        PNX_HIP(hipMemcpyAsync(rnorm + off, S.r, c * sizeof(double), hipMemcpyDeviceToHost, s));
+        PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, S.tc, c * P.n_bins * sizeof(T), hipMemcpyDeviceToHost, s));
+        PNX_HIP(hipMemcpyAsync(rnorm + off, S.tr, c * sizeof(T), hipMemcpyDeviceToHost, s));
         if (status) PNX_HIP(hipMemcpyAsync(status + off, S.s, c, hipMemcpyDeviceToHost, s));
         if (iters) PNX_HIP(hipMemcpyAsync(iters + off, S.i, c * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         return PNX_OK;
     };
     return run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+}
+
+extern "C" {
+int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
+                       double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream) {
+    return nnls_solve<double>(plan, n_vox, y, max_iter, coeff, rnorm, status, iters, mem, stream);
+}
+
+int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int max_iter, float *coeff, float *rnorm,
+                       int8_t *status, int32_t *iters, int mem, void *stream) {
+    return nnls_solve<float>(plan, n_vox, y, max_iter, coeff, rnorm, status, iters, mem, stream);
 }
 
 int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream) {

@@ -41,7 +41,6 @@ constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
 constexpr int kNone = 1 << 30;
 constexpr int kGBatch = 4;  // rows of G in flight per lane in the dual update
-constexpr int64_t kAtyChunk = 1 << 20;  // voxels per MFMA Gram step / active-set launch pair
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
 struct NnlsArgs {
@@ -821,7 +820,7 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
 
 int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream) {
     if (!P->aty) return set_error(PNX_ERR_UNSUPPORTED, "the MFMA Gram step is disabled for this plan (n_meas=%d)", P->n_meas);
-    if (n_vox > kAtyChunk) return set_error(PNX_ERR_INVALID, "n_vox=%lld > %d per call", (long long)n_vox, kAtyChunk);
+    if (n_vox > kAtyChunk) return set_error(PNX_ERR_INVALID, "n_vox=%lld > %lld per call", (long long)n_vox, (long long)kAtyChunk);
     const int kpad = (P->n_meas + 3) & ~3;
     const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);
     const long long strips = (n_vox + 15) / 16;

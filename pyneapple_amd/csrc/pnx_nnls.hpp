@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 namespace pnx {
+constexpr int64_t kAtyChunk = 1 << 20;  // voxels per MFMA Gram step / active-set launch pair
+
 
 constexpr int kNnlsMaxBins = 256;  // 4 bins per lane
 constexpr int kNnlsMaxMeas = 128;

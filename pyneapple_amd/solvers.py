@@ -76,6 +76,13 @@ def kernel_t1(model) -> dict:
     return dict(t1_mode=2 if steam else 1, tr=float(tr), tm=float(tm) if steam else 0.0)
 
 
+def _io_dtype(name):
+    name = str(np.dtype(name)) if not isinstance(name, str) else name
+    if name not in ("float64", "float32"):
+        raise ValueError("io_dtype must be 'float64' or 'float32'")
+    return np.float32 if name == "float32" else np.float64
+
+
 def _split(n: int, parts: int):
     edges = np.linspace(0, n, parts + 1).astype(np.int64)
     return [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
@@ -88,6 +95,10 @@ class HipCurveFitSolver(CurveFitBase):
         jacobian: "fd" (default; SciPy 2-point finite differences, what the reference uses when no parameter
             is fixed) or "analytic" (model Jacobian; always used when parameters are fixed, like the reference).
         device: first HIP device index (default 0).  n_gpus: number of devices to shard voxels over (default 1).
+        io_dtype: "float64" (default, the reference's array types) or "float32": signals, start values, bounds and
+            fixed maps cross the ABI as float32 and results come back as float32 (pnx_curvefit_batch_f32); the
+            arithmetic stays fp64 -- for float32 images this is what the reference computes, without the float64
+            host copy.
     """
 
     def __init__(self, model: Any, max_iter: int, tol: float, p0: dict[str, float],
@@ -96,6 +107,7 @@ class HipCurveFitSolver(CurveFitBase):
         self.jacobian_mode = str(solver_kwargs.pop("jacobian", "fd"))
         self.device = int(solver_kwargs.pop("device", 0))
         self.n_gpus = int(solver_kwargs.pop("n_gpus", 1))
+        self.io_dtype = _io_dtype(solver_kwargs.pop("io_dtype", "float64"))
         if self.jacobian_mode not in ("fd", "analytic"):
             raise ValueError("jacobian must be 'fd' or 'analytic'")
         if method != "trf":
@@ -225,7 +237,7 @@ class HipCurveFitSolver(CurveFitBase):
                 fixed_vals = np.array([float(fixed[all_names[i]]) for i in fixed_idx])
             jac = "analytic"  # the reference passes model.jacobian_with_fixed here (curvefit.py:279-281)
 
-        res = self._run(xdata, np.ascontiguousarray(ydata, np.float64), p0_a, lo_a, hi_a, per_voxel, fixed_idx,
+        res = self._run(xdata, np.ascontiguousarray(ydata, self.io_dtype), p0_a, lo_a, hi_a, per_voxel, fixed_idx,
                         fixed_vals, jac)
         popt, pcov, status = res["popt"], res["pcov"], res["status"]
         success = status > 0
@@ -274,6 +286,7 @@ class HipNNLSSolver(NNLSBase):
                  verbose=False, multi_threading: bool = False, **solver_kwargs: Any) -> None:
         self.device = int(solver_kwargs.pop("device", 0))
         self.n_gpus = int(solver_kwargs.pop("n_gpus", 1))
+        self.io_dtype = _io_dtype(solver_kwargs.pop("io_dtype", "float64"))  # "float32": fp32 signal in / spectra out
         if HAVE_PYNEAPPLE:
             super().__init__(model, reg_order=reg_order, mu=mu, max_iter=max_iter, tol=tol, verbose=verbose,
                              multi_threading=multi_threading, **solver_kwargs)
@@ -298,7 +311,7 @@ class HipNNLSSolver(NNLSBase):
     def fit(self, xdata: np.ndarray, signal: np.ndarray, pixel_fixed_params=None, **kwargs) -> "HipNNLSSolver":
         self._reset_state()
         xdata = np.asarray(xdata, float)
-        signal = np.asarray(signal, float)
+        signal = np.asarray(signal, self.io_dtype)
         basis = np.asarray(self.model.get_basis(xdata), float)
         reg = self.get_regularization_matrix()
         if signal.ndim == 1:
