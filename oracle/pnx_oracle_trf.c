@@ -26,6 +26,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -697,6 +698,10 @@ static void compute_jac(prob_t *P, int jac_mode, const double *x, const double *
 
 /* status: 1..4 scipy termination (success), 0 = max_nfev reached, -1 lb>=ub, -2 non-finite signal,
  * -3 p0 outside bounds, -4 non-finite residual at p0 (same codes as include/pnx.h) */
+/* debugging aid: pnxo_set_trace(1) prints one line per function evaluation of the next fits to stderr */
+static int g_trace = 0;
+void pnxo_set_trace(int on) { g_trace = on; }
+
 static int fit_one(prob_t *P, const double *p0, const double *lb, const double *ub, int max_nfev, double ftol,
                    double xtol, double gtol, int jac_mode, double *xout, double *pcov, int *nfev_out, double *cost_out,
                    int *njev_out)
@@ -784,6 +789,12 @@ static int fit_one(prob_t *P, const double *p0, const double *lb, const double *
             }
             cost_new = 0.5 * vdot(f_new, f_new, m);
             actual_reduction = cost - cost_new;
+            if (g_trace) {
+                fprintf(stderr, "[pnxo] nfev %d Delta %.17g alpha %.17g more_iters %d predicted %.17g cost_new %.17g step_h_norm %.17g step",
+                        nfev, Delta, alpha, n_iter, predicted_reduction, cost_new, step_h_norm);
+                for (int i = 0; i < n; ++i) fprintf(stderr, " %.17g", step[i]);
+                fprintf(stderr, "\n");
+            }
             /* common.py:222-245 update_tr_radius */
             double ratio;
             if (predicted_reduction > 0)
