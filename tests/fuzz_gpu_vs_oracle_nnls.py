@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP NNLS path against the oracle (run by hand on a GPU box:
+`python tests/fuzz_gpu_vs_oracle_nnls.py [n_cases] [seed]`).  Random number of measurements (3..64) and bins (4..256),
+D range, regulariser (none, orders 0-3, a dense random matrix), mu, signal scale 1e-6..1e6, noise, number of
+compartments, iteration limit (tiny, default, 0 = SciPy's 3 n).  With a regulariser of full column rank the minimiser
+is unique: coefficients are compared (1e-6 of the spectrum peak), as are status, rnorm and the iteration counts.
+Without one (or order 0) only status, rnorm and non-negativity are compared."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pnx_oracle as oracle  # noqa: E402
+from pyneapple_amd import api  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    tot = coef_bad = stat_bad = iter_bad = rn_bad = 0
+    for c in range(n_cases):
+        n_meas = int(rng.integers(3, 65))
+        n_bins = int(rng.choice([4, 7, 16, 50, 63, 64, 65, 128, 250, 256]))
+        n_vox = int(rng.choice([1, 5, 64, 200]))
+        b = np.sort(rng.uniform(0, float(rng.choice([800, 1500])), n_meas))
+        b[0] = 0.0
+        bins = api.nnls_bins(10.0 ** rng.uniform(-4.5, -3), 10.0 ** rng.uniform(-1.5, 0), n_bins)
+        basis = np.exp(-np.outer(b, bins))
+        kind = str(rng.choice(["none", "o0", "o1", "o2", "o3", "dense"]))
+        mu = float(rng.choice([0.002, 0.02, 0.5]))
+        if kind == "none":
+            reg = None
+        elif kind == "dense":
+            reg = mu * rng.standard_normal((n_bins + 3, n_bins))
+        else:
+            reg = api.nnls_regularization_matrix(n_bins, int(kind[1]), mu)
+        scale = float(10.0 ** rng.integers(-6, 7))
+        ncomp = int(rng.integers(1, 4))
+        D = 10.0 ** rng.uniform(-3.3, -1.2, (n_vox, ncomp))
+        w = rng.uniform(0.2, 1.0, (n_vox, ncomp))
+        y = np.einsum("vc,vcm->vm", w, np.exp(-D[:, :, None] * b[None, None, :])) * scale
+        y *= 1 + float(rng.choice([0.0, 0.01, 0.1])) * rng.standard_normal(y.shape)
+        if rng.random() < 0.15:
+            y[rng.integers(n_vox), rng.integers(n_meas)] = np.nan
+        max_iter = int(rng.choice([250, 250, 0, 3, 20]))
+        desc = f"n_meas={n_meas} n_bins={n_bins} n_vox={n_vox} reg={kind} mu={mu} scale={scale:g} comps={ncomp} max_iter={max_iter}"
+        try:
+            r = api.nnls(basis, reg, y, max_iter)
+        except Exception as e:
+            print(f"[case {c}] GPU raised {e!r}: {desc}")
+            bad += 1
+            continue
+        o = oracle.nnls(basis, reg, y, max_iter, n_threads=8)
+        tot += n_vox
+        sb = r["status"] != o["status"]
+        ok = (r["status"] == 1) & (o["status"] == 1)
+        unique = kind in ("o1", "o2", "o3", "dense")
+        peak = np.abs(o["coefficients"]).max(axis=1) + 1e-300
+        ce = np.abs(r["coefficients"] - o["coefficients"]).max(axis=1) / peak
+        cb = ok & (ce > 1e-6) if unique else np.zeros(n_vox, bool)
+        # without a regulariser the system is rank deficient and often exactly solvable: rnorm is then rounding noise
+        # times the condition number -- compare it against the signal norm there
+        ynorm = np.linalg.norm(np.nan_to_num(y), axis=1)
+        rb = ok & (np.abs(r["residual"] - o["residual"]) > 1e-8 * np.abs(o["residual"]) + (1e-12 if unique else 1e-7) * ynorm)
+        ib = ok & (r["iters"] != o["iters"]) if unique else np.zeros(n_vox, bool)
+        neg = (r["coefficients"] < 0).any()
+        fail_same = (r["status"] != 1) & (o["status"] != 1)
+        sent = fail_same & ((r["coefficients"] != 0).any(axis=1) | ~np.isclose(r["residual"], o["residual"], rtol=1e-12, equal_nan=True))
+        stat_bad += int(sb.sum()); coef_bad += int(cb.sum()); rn_bad += int(rb.sum()); iter_bad += int(ib.sum())
+        if sb.any() or cb.any() or rb.any() or neg or sent.any() or ib.sum() > 0.02 * n_vox + 1:
+            hard = sb.any() or cb.any() or rb.any() or neg or sent.any()
+            print(f"[case {c}] {'FAIL' if hard else 'note'}: status {int(sb.sum())} coeff {int(cb.sum())} rnorm {int(rb.sum())} iters {int(ib.sum())} "
+                  f"sentinel {int(sent.sum())} negative {bool(neg)} of {n_vox}: {desc}")
+            if sb.any():
+                i = int(np.nonzero(sb)[0][0]); print(f"      voxel {i}: gpu status {r['status'][i]} iters {r['iters'][i]} | oracle {o['status'][i]} iters {o['iters'][i]}")
+            elif cb.any():
+                i = int(np.nonzero(cb)[0][0]); print(f"      voxel {i}: coeff err {ce[i]:.3g} of peak, iters gpu {r['iters'][i]} oracle {o['iters'][i]}, rnorm gpu {r['residual'][i]:.12g} oracle {o['residual'][i]:.12g}")
+            bad += bool(hard)
+    print(f"{n_cases} cases, {tot} voxels: status {stat_bad}, coefficients {coef_bad}, rnorm {rn_bad}, iteration-count {iter_bad} disagreements; failing cases {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
