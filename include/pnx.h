@@ -179,6 +179,22 @@ int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, 
 int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg);
 
 /*
+ * IDEAL level plumbing on the device.
+ * pnx_resize2d_f64: resize the first two axes of an (X, Y, C) array (C = product of the trailing axes, contiguous)
+ *   to (TX, TY, C) with OpenCV's INTER_LINEAR (method 0) / INTER_CUBIC (method 1) arithmetic -- half-pixel centres,
+ *   cubic a = -0.75, replicated border, no anti-aliasing.  Replaces IDEALFitter._interpolate_array, which calls
+ *   cv2.resize per slice and channel (fitters/ideal.py:299-320).  in / out: host or device (mem).
+ * pnx_ideal_bounds_f64: from a parameter map (n_px, n_params) -- the previous level's result, resized -- the next
+ *   level's start values and bounds, parameter-major (n_params, n_px): p0 = clip(map, lo, hi),
+ *   lower = clip(p0 (1 - tol), lo, hi), upper = clip(p0 (1 + tol), lo, hi)  (ideal.py:167-198).  Device pointers;
+ *   lo / hi / tol (n_params,) on the host.
+ */
+int pnx_resize2d_f64(const double *in, int X, int Y, int64_t C, double *out, int TX, int TY, int method, int mem,
+                     int device, void *stream);
+int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const double *lo_host, const double *hi_host,
+                         const double *tol_host, double *p0, double *lower, double *upper, int device, void *stream);
+
+/*
  * Residual / Jacobian / normal-equation sweep at given parameters (one pass of the LM inner loop as a
  * standalone, HBM-streaming kernel): for every voxel reads y (n_b) and params (n_all), writes
  * cost = 0.5*||r||^2, g = J^T r (n_all) and the upper triangle of J^T J (n_all(n_all+1)/2).

@@ -20,7 +20,8 @@ N_MODELS = 7
 
 
 def _units():
-    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", []), ("pnx_sweep.o", "pnx_sweep.hip", [])]
+    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", []), ("pnx_sweep.o", "pnx_sweep.hip", []),
+             ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
         units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}"]))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]

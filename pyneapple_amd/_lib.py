@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "pnx_curvefit_batch_f32", "pnx_nnls_solve_f32",
     "pnx_nnls_plan_create", "pnx_nnls_plan_destroy", "pnx_nnls_solve_f64", "pnx_nnls_aty_f64", "pnx_nnls_batch_f64",
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
+    "pnx_resize2d_f64", "pnx_ideal_bounds_f64",
 ]
 
 
@@ -104,6 +105,10 @@ def load():
     lib.pnx_nnls_plan_destroy.argtypes = [vp]
     lib.pnx_nnls_solve_f64.restype = C.c_int
     lib.pnx_nnls_solve_f64.argtypes = [vp, C.c_int64, dp, C.c_int, dp, dp, vp, vp, C.c_int, vp]
+    lib.pnx_resize2d_f64.restype = C.c_int
+    lib.pnx_resize2d_f64.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.pnx_ideal_bounds_f64.restype = C.c_int
+    lib.pnx_ideal_bounds_f64.argtypes = [vp, C.c_int64, C.c_int, dp, dp, dp, vp, vp, vp, C.c_int, vp]
     lib.pnx_nnls_solve_f32.restype = C.c_int
     lib.pnx_nnls_solve_f32.argtypes = lib.pnx_nnls_solve_f64.argtypes
     lib.pnx_nnls_aty_f64.restype = C.c_int

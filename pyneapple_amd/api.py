@@ -189,6 +189,34 @@ def nnls_basis(b, bins, device=0):
     return out
 
 
+_RESIZE_METHODS = {"linear": 0, "cubic": 1}
+
+
+def resize2d(array, target_shape, method="cubic", device=0):
+    """Resize the first two axes of a float64 numpy array (X, Y, ...) on the device (pnx_resize2d_f64, host arrays)."""
+    _lib.require_device()
+    a = np.ascontiguousarray(array, np.float64)
+    tx, ty = int(target_shape[0]), int(target_shape[1])
+    c = int(np.prod(a.shape[2:], dtype=np.int64)) if a.ndim > 2 else 1
+    out = np.empty((tx, ty) + a.shape[2:])
+    check(load().pnx_resize2d_f64(ptr(a), a.shape[0], a.shape[1], c, ptr(out), tx, ty, _RESIZE_METHODS[method], MEM_HOST,
+                                  int(device), None))
+    return out
+
+
+def resize2d_device(src, x, y, c, dst, tx, ty, method, device, stream=None):
+    """Enqueue the resize on HBM-resident float64 tensors: src (x, y, c) -> dst (tx, ty, c)."""
+    check(load().pnx_resize2d_f64(ptr(src), int(x), int(y), int(c), ptr(dst), int(tx), int(ty), _RESIZE_METHODS[method],
+                                  MEM_DEVICE, int(device), stream))
+
+
+def ideal_bounds_device(param_map, n_px, lo, hi, tol, p0, lower, upper, device, stream=None):
+    """Enqueue p0 / lower / upper (n_params, n_px) of the next IDEAL level from a resized map (n_px, n_params)."""
+    lo, hi, tol = (np.ascontiguousarray(a, np.float64) for a in (lo, hi, tol))
+    check(load().pnx_ideal_bounds_f64(ptr(param_map), int(n_px), int(lo.size), ptr(lo), ptr(hi), ptr(tol), ptr(p0), ptr(lower),
+                                      ptr(upper), int(device), stream))
+
+
 def sweep_device(model, n_vox, b, y, params, cost, g, jtj, device, stream=None):
     """Enqueue one residual/Jacobian/normal-equation sweep on HBM-resident torch tensors (f32 or f64)."""
     import torch

@@ -1,0 +1,185 @@
+// pnx_resize.hip -- separable resize of the first two axes of an (X, Y, C) fp64 array with OpenCV's INTER_LINEAR /
+// INTER_CUBIC arithmetic (half-pixel centres, cubic a = -0.75, replicated border, no anti-aliasing), and the
+// element-wise step that turns a resized parameter map into the start values and bounds of the next IDEAL level.
+// Reference: IDEALFitter._interpolate_array calls cv2.resize per slice and channel (fitters/ideal.py:299-320) and
+// derives p0 / bounds per level (ideal.py:167-198).  One thread per output element, channel index fastest (the
+// (Z, N) axes are contiguous), so loads and stores are coalesced; HBM bound.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "pnx_internal.hpp"
+
+namespace pnx {
+
+struct Taps {  // per output coordinate: 4 source indices and weights (linear: 2 used, rest weight 0)
+    int idx[4];
+    double w[4];
+};
+
+static void make_taps(int n_src, int n_dst, int method, std::vector<Taps> &t) {
+    t.resize(n_dst);
+    const double scale = (double)n_src / n_dst;
+    for (int d = 0; d < n_dst; ++d) {
+        const double f = (d + 0.5) * scale - 0.5;
+        int s = (int)std::floor(f);
+        double fr = f - s;
+        Taps &T = t[d];
+        for (int k = 0; k < 4; ++k) {
+            T.idx[k] = 0;
+            T.w[k] = 0;
+        }
+        if (method == 0) {  // INTER_LINEAR
+            if (s < 0) {
+                s = 0;
+                fr = 0;
+            }
+            if (s >= n_src - 1) {
+                s = n_src - 1;
+                fr = 0;
+            }
+            T.idx[0] = s;
+            T.w[0] = 1.0 - fr;
+            T.idx[1] = s + 1 < n_src ? s + 1 : n_src - 1;
+            T.w[1] = fr;
+        } else {  // INTER_CUBIC, A = -0.75
+            const double A = -0.75, x = fr;
+            const double c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+            const double c1 = ((A + 2) * x - (A + 3)) * x * x + 1;
+            const double c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+            const double c[4] = {c0, c1, c2, 1.0 - c0 - c1 - c2};
+            for (int k = 0; k < 4; ++k) {
+                int i = s - 1 + k;
+                i = i < 0 ? 0 : (i >= n_src ? n_src - 1 : i);
+                T.idx[k] = i;
+                T.w[k] = c[k];
+            }
+        }
+    }
+}
+
+__global__ void resize2d_kernel(const double *__restrict__ in, double *__restrict__ out, const Taps *__restrict__ tx,
+                                const Taps *__restrict__ ty, int Y, long long C, int TX, int TY) {
+    const long long total = (long long)TX * TY * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long c = e % C;
+        const long long xy = e / C;
+        const int oy = (int)(xy % TY), ox = (int)(xy / TY);
+        const Taps a = tx[ox], b = ty[oy];
+        // rows first, then columns -- the order of the numpy restatement (ideal.py resize2d: Wx, then Wy)
+        double acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double col = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) col += a.w[i] * in[((long long)a.idx[i] * Y + b.idx[j]) * C + c];
+            acc += b.w[j] * col;
+        }
+        out[e] = acc;
+    }
+}
+
+// p0 = clip(map, lo, hi); lower = clip(p0 (1 - tol), lo, hi); upper = clip(p0 (1 + tol), lo, hi), written
+// parameter-major (n_params, n_px) -- the layout the solver takes (ideal.py:182-189, validation.py:177-203).
+// `map` is (n_px, n_params) (a parameter map with the parameter axis last).
+__global__ void ideal_bounds_kernel(const double *__restrict__ map, long long n_px, int n_params, const double *__restrict__ lo,
+                                    const double *__restrict__ hi, const double *__restrict__ tol, double *__restrict__ p0,
+                                    double *__restrict__ lower, double *__restrict__ upper) {
+    const long long total = n_px * n_params;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e / n_px);
+        const long long v = e - (long long)k * n_px;
+        const double l = lo[k], h = hi[k], t = tol[k];
+        double p = map[v * n_params + k];
+        p = fmin(fmax(p, l), h);
+        p0[e] = p;
+        lower[e] = fmin(fmax(p * (1 - t), l), h);
+        upper[e] = fmin(fmax(p * (1 + t), l), h);
+    }
+}
+
+}  // namespace pnx
+
+using namespace pnx;
+
+#define RS_HIP(call)                                                                                 \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" {
+
+int pnx_resize2d_f64(const double *in, int X, int Y, int64_t C, double *out, int TX, int TY, int method, int mem, int device,
+                     void *stream) {
+    if (!in || !out) return set_error(PNX_ERR_INVALID, "NULL pointer");
+    if (X < 1 || Y < 1 || C < 1 || TX < 1 || TY < 1) return set_error(PNX_ERR_INVALID, "bad resize shape");
+    if (method != 0 && method != 1) return set_error(PNX_ERR_INVALID, "method %d (0 linear, 1 cubic)", method);
+    if (mem != PNX_MEM_HOST && mem != PNX_MEM_DEVICE) return set_error(PNX_ERR_INVALID, "mem=%d", mem);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_error(PNX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
+    RS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<Taps> tx, ty;
+    make_taps(X, TX, method, tx);
+    make_taps(Y, TY, method, ty);
+    Taps *dtx = nullptr, *dty = nullptr;
+    RS_HIP(hipMallocAsync((void **)&dtx, sizeof(Taps) * TX, st));
+    RS_HIP(hipMallocAsync((void **)&dty, sizeof(Taps) * TY, st));
+    RS_HIP(hipMemcpyAsync(dtx, tx.data(), sizeof(Taps) * TX, hipMemcpyHostToDevice, st));
+    RS_HIP(hipMemcpyAsync(dty, ty.data(), sizeof(Taps) * TY, hipMemcpyHostToDevice, st));
+    RS_HIP(hipStreamSynchronize(st));  // the tap tables live in pageable host vectors that die with this call
+    const size_t n_in = (size_t)X * Y * C, n_out = (size_t)TX * TY * C;
+    const double *din = in;
+    double *dout = out;
+    double *tmp_in = nullptr, *tmp_out = nullptr;
+    if (mem == PNX_MEM_HOST) {
+        RS_HIP(hipMalloc((void **)&tmp_in, n_in * sizeof(double)));
+        RS_HIP(hipMalloc((void **)&tmp_out, n_out * sizeof(double)));
+        RS_HIP(hipMemcpyAsync(tmp_in, in, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+        din = tmp_in;
+        dout = tmp_out;
+    }
+    size_t blocks = (n_out + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(resize2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, din, dout, dtx, dty, Y, (long long)C, TX, TY);
+    RS_HIP(hipGetLastError());
+    RS_HIP(hipFreeAsync(dtx, st));
+    RS_HIP(hipFreeAsync(dty, st));
+    if (mem == PNX_MEM_HOST) {
+        RS_HIP(hipMemcpyAsync(out, tmp_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+        RS_HIP(hipStreamSynchronize(st));
+        (void)hipFree(tmp_in);
+        (void)hipFree(tmp_out);
+    }
+    return PNX_OK;
+}
+
+int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const double *lo_host, const double *hi_host,
+                         const double *tol_host, double *p0, double *lower, double *upper, int device, void *stream) {
+    if (!map || !lo_host || !hi_host || !tol_host || !p0 || !lower || !upper) return set_error(PNX_ERR_INVALID, "NULL pointer");
+    if (n_px < 0 || n_params < 1 || n_params > PNX_MAX_PARAMS) return set_error(PNX_ERR_INVALID, "bad sizes");
+    if (n_px == 0) return PNX_OK;
+    RS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    double *d = nullptr;
+    RS_HIP(hipMallocAsync((void **)&d, sizeof(double) * 3 * PNX_MAX_PARAMS, st));
+    double h[3 * PNX_MAX_PARAMS] = {0};
+    for (int k = 0; k < n_params; ++k) {
+        h[k] = lo_host[k];
+        h[PNX_MAX_PARAMS + k] = hi_host[k];
+        h[2 * PNX_MAX_PARAMS + k] = tol_host[k];
+    }
+    RS_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st));
+    RS_HIP(hipStreamSynchronize(st));  // h is on this stack frame
+    size_t blocks = ((size_t)n_px * n_params + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ideal_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map, (long long)n_px, n_params, d,
+                       d + PNX_MAX_PARAMS, d + 2 * PNX_MAX_PARAMS, p0, lower, upper);
+    RS_HIP(hipGetLastError());
+    RS_HIP(hipFreeAsync(d, st));
+    return PNX_OK;
+}
+}

@@ -61,6 +61,8 @@ def resize2d(array: np.ndarray, target_shape, method: str = "cubic") -> np.ndarr
     tx, ty = int(target_shape[0]), int(target_shape[1])
     if array.dtype.kind != "f":
         array = array.astype(np.float32)  # ideal.py:309-310
+    if (tx, ty) == tuple(array.shape[:2]):
+        return array  # cv2.resize to the same size returns the input values (last pyramid level: no 1 GB copy)
     Wx = resize_weights(array.shape[0], tx, method).astype(array.dtype)
     Wy = resize_weights(array.shape[1], ty, method).astype(array.dtype)
     out = np.tensordot(Wx, array, axes=(1, 0))            # (tx, Y, ...)
@@ -78,7 +80,7 @@ class HipIDEALFitter:
     """
 
     def __init__(self, solver, dim_steps, step_tol: dict, ideal_dims: int = 2, segmentation_threshold: float = 0.2,
-                 interpolation_method: str = "cubic", **fitter_kwargs):
+                 interpolation_method: str = "cubic", device_resident: bool | None = None, **fitter_kwargs):
         if interpolation_method not in _INTERPOLATION_METHODS:
             raise ValueError(
                 f"Invalid interpolation method: {interpolation_method}. Must be one of {_INTERPOLATION_METHODS}.")
@@ -88,6 +90,10 @@ class HipIDEALFitter:
         self.ideal_dims = ideal_dims
         self.segmentation_threshold = segmentation_threshold
         self.interpolation_method = interpolation_method
+        # True: the whole pyramid stays in HBM (image uploaded once, resize / bounds / fits on the device, maps downloaded
+        # per level); False: numpy resize + host-array solver calls; None: device resident when the solver is a
+        # HipCurveFitSolver without fixed parameters and torch (device memory) is importable
+        self.device_resident = device_resident
         self.step_params: list[np.ndarray] = []
         self.fitted_params_: dict = {}
         self.pixel_indices = None
@@ -144,9 +150,14 @@ class HipIDEALFitter:
         lo_vals = np.array([self.solver.bounds[n][0] for n in names], float)
         hi_vals = np.array([self.solver.bounds[n][1] for n in names], float)
         tol_vals = np.array([self.step_tol[n] for n in names], float)
+        if self._use_device_path():
+            return self._fit_device(xdata, image, segmentation, dim_steps, names, p0_vals, lo_vals, hi_vals, tol_vals, t0,
+                                    fit_kwargs)
         self.step_params = []
+        self.stage_times_ = []  # per level: seconds spent resizing / masking, in solver.fit, in map assembly
         method = self.interpolation_method
         for step_index, step in enumerate(dim_steps):
+            t_a = time.perf_counter()
             shape = tuple(int(s) for s in step)
             if step_index == 0:
                 p0 = np.broadcast_to(p0_vals, (*shape, n_params)).copy()
@@ -162,14 +173,117 @@ class HipIDEALFitter:
                 mask = np.ones(shape, dtype=bool)
             pixels = np.ascontiguousarray(img[mask], dtype=np.float64)       # (n_px, N), C order of np.where
             idx = np.nonzero(mask)
+            t_b = time.perf_counter()
             self.solver.fit(xdata, pixels, p0=np.ascontiguousarray(p0[mask].T),
                             bounds=(np.ascontiguousarray(lower[mask].T), np.ascontiguousarray(upper[mask].T)),
                             **fit_kwargs)
+            t_c = time.perf_counter()
             param_map = np.zeros((*shape, n_params))
             for k, n in enumerate(names):
                 param_map[idx[0], idx[1], idx[2], k] = np.atleast_1d(self.solver.params_[n])
             self.step_params.append(param_map)
-        self.pixel_indices = list(zip(*idx))
+            self.stage_times_.append((round(t_b - t_a, 3), round(t_c - t_b, 3), round(time.perf_counter() - t_c, 3)))
+        self.pixel_indices = np.stack(idx, axis=1)  # (n_px, 3), C order of np.where
         self.fitted_params_ = dict(self.solver.params_)
+        self.fit_time = time.perf_counter() - t0
+        return self
+
+    # ------------------------------------------------------------------ device-resident pyramid
+    def _use_device_path(self) -> bool:
+        if self.device_resident is False:
+            return False
+        s = self.solver
+        ok = hasattr(s, "_kernel_model") and hasattr(s, "_pack") and not (getattr(s.model, "fixed_params", None) or None) \
+            and getattr(s, "n_gpus", 1) == 1 and getattr(s, "io_dtype", np.float64) is np.float64
+        if ok:
+            try:
+                import torch  # noqa: F401  (device memory only)
+            except Exception:
+                ok = False
+        if self.device_resident and not ok:
+            raise ValueError("device_resident=True needs a single-GPU HipCurveFitSolver without fixed parameters and torch")
+        return ok
+
+    def _fit_device(self, xdata, image, segmentation, dim_steps, names, p0_vals, lo_vals, hi_vals, tol_vals, t0, fit_kwargs):
+        """Same level loop as above with everything between the first upload and the per-level map download in HBM:
+        pnx_resize2d_f64 (image, mask, previous maps), pnx_ideal_bounds_f64 (p0 / bounds of the level) and the
+        device-pointer fit (pnx_curvefit_batch_f64, per-voxel p0 / bounds).  torch only allocates and indexes."""
+        import torch
+
+        from . import api
+
+        s = self.solver
+        dev_i = int(s.device)
+        dev = torch.device("cuda", dev_i)
+        torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        method = self.interpolation_method
+        X, Y, Z, N = image.shape
+        n = len(names)
+        img_d = torch.from_numpy(np.ascontiguousarray(image, np.float64)).to(dev)
+        seg_d = torch.from_numpy(np.ascontiguousarray(segmentation, np.float64)).to(dev)  # ideal.py:309-310 casts the mask to float
+        kw = dict(s._kernel_t1)
+        self.step_params, self.stage_times_ = [], []
+        prev = None  # (px, py, Z, n) device map of the previous level
+        for step_index, step in enumerate(dim_steps):
+            t_a = time.perf_counter()
+            tx, ty = int(step[0]), int(step[1])
+            shape = (tx, ty, Z)
+
+            def resize(src, c):
+                sx, sy = int(src.shape[0]), int(src.shape[1])
+                if (sx, sy) == (tx, ty):
+                    return src
+                dst = torch.empty((tx, ty) + tuple(src.shape[2:]), dtype=torch.float64, device=dev)
+                api.resize2d_device(src, sx, sy, c, dst, tx, ty, method, dev_i, stream)
+                return dst
+
+            img_l = resize(img_d, Z * N)
+            mask = resize(seg_d, Z) > self.segmentation_threshold
+            if not bool(mask.any()):
+                mask = torch.ones(shape, dtype=torch.bool, device=dev)
+            all_px = bool(mask.all())
+            idx = None if all_px else mask.reshape(-1).nonzero().squeeze(1)
+            n_px = tx * ty * Z if all_px else int(idx.numel())
+            pixels = img_l.reshape(-1, N) if all_px else img_l.reshape(-1, N).index_select(0, idx)
+            per_voxel = prev is not None
+            if per_voxel:
+                m = resize(prev, Z * n).reshape(-1, n)
+                if not all_px:
+                    m = m.index_select(0, idx)
+                p0_d = torch.empty((n, n_px), dtype=torch.float64, device=dev)
+                lo_d, hi_d = torch.empty_like(p0_d), torch.empty_like(p0_d)
+                api.ideal_bounds_device(m.contiguous(), n_px, lo_vals, hi_vals, tol_vals, p0_d, lo_d, hi_d, dev_i, stream)
+                p0_a, lo_a, hi_a = p0_d, lo_d, hi_d
+            else:
+                p0_a, lo_a, hi_a = p0_vals, lo_vals, hi_vals
+            last = step_index == len(dim_steps) - 1
+            popt = torch.empty((n, n_px), dtype=torch.float64, device=dev)
+            status = torch.empty(n_px, dtype=torch.int8, device=dev)
+            nfev = torch.empty(n_px, dtype=torch.int32, device=dev)
+            cost = torch.empty(n_px, dtype=torch.float64, device=dev)
+            pcov = torch.empty((n_px, n, n), dtype=torch.float64, device=dev) if last else None
+            opts = api.make_opts(s._kernel_model, N, [], per_voxel, False, int(s.max_iter), float(s.tol), 1e-8, 1e-8,
+                                 s.jacobian_mode, kw["t1_mode"], kw["tr"], kw["tm"])
+            t_b = time.perf_counter()
+            api.curvefit_device(opts, n_px, xdata, pixels.contiguous(), p0_a, lo_a, hi_a, None, popt, pcov, status, nfev, cost,
+                                dev_i, stream)
+            if all_px:
+                pmap = popt.t().contiguous().reshape(tx, ty, Z, n)
+            else:
+                pmap = torch.zeros((tx * ty * Z, n), dtype=torch.float64, device=dev)
+                pmap.index_copy_(0, idx, popt.t().contiguous())
+                pmap = pmap.reshape(tx, ty, Z, n)
+            torch.cuda.synchronize(dev)
+            t_c = time.perf_counter()
+            self.step_params.append(pmap.cpu().numpy())
+            prev = pmap
+            self.stage_times_.append((round(t_b - t_a, 3), round(t_c - t_b, 3), round(time.perf_counter() - t_c, 3)))
+        res = {"popt": popt.cpu().numpy(), "pcov": pcov.cpu().numpy(), "status": status.cpu().numpy(),
+               "nfev": nfev.cpu().numpy(), "cost": cost.cpu().numpy()}
+        s._reset_state()
+        s._pack(res, n_px, list(names))  # the solver ends in the state solver.fit() of the last level leaves it in
+        self.pixel_indices = (torch.ones(shape, dtype=torch.bool) if all_px else mask.cpu()).nonzero().numpy()
+        self.fitted_params_ = dict(s.params_)
         self.fit_time = time.perf_counter() - t0
         return self

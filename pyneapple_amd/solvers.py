@@ -239,6 +239,11 @@ class HipCurveFitSolver(CurveFitBase):
 
         res = self._run(xdata, np.ascontiguousarray(ydata, self.io_dtype), p0_a, lo_a, hi_a, per_voxel, fixed_idx,
                         fixed_vals, jac)
+        self._pack(res, n_pixels, free_names)
+        return self
+
+    def _pack(self, res, n_pixels, free_names):
+        """Result dict of the batch call -> the reference's solver state (curvefit.py:150-159, 214-244)."""
         popt, pcov, status = res["popt"], res["pcov"], res["status"]
         success = status > 0
         params_rows = np.ascontiguousarray(popt.T)
@@ -246,9 +251,8 @@ class HipCurveFitSolver(CurveFitBase):
             params_rows, pcov, success,
             lambda i, st=status: None if st[i] > 0 else _CURVEFIT_MESSAGES.get(int(st[i]), "fit failed"))
         self.params_ = {name: [float(popt[i, 0])] if n_pixels == 1 else popt[i] for i, name in enumerate(free_names)}
-        self.diagnostics_ = {"pcov": pcov[0] if n_pixels == 1 else pcov, "n_pixels": n_pixels,
+        self.diagnostics_ = {"pcov": (pcov[0] if n_pixels == 1 else pcov) if pcov is not None else None, "n_pixels": n_pixels,
                              "status": status, "nfev": res["nfev"], "cost": res["cost"]}
-        return self
 
     def _run(self, xdata, ydata, p0, lo, hi, per_voxel, fixed_idx, fixed_vals, jac):
         n_vox = ydata.shape[0]

@@ -130,3 +130,57 @@ def test_three_level_pyramid_on_gpu(gpu):
     assert np.median(np.abs(final[..., 0] - f1) / f1) < 0.05
     assert np.median(np.abs(final[..., 2] - D2) / D2) < 0.05
     assert (np.asarray(solver.diagnostics_["status"]) > 0).mean() > 0.95
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_device_resize_matches_numpy_restatement(gpu, method):
+    """pnx_resize2d_f64 against the numpy statement of OpenCV's arithmetic (resize2d), down- and up-scaling, odd sizes."""
+    rng = np.random.default_rng(1)
+    for src, dst in (((13, 9, 3, 5), (5, 4)), ((6, 7, 2), (19, 16)), ((8, 8, 1, 2), (8, 8)), ((5, 11), (10, 3))):
+        a = rng.standard_normal(src)
+        want = resize2d(a, dst, method)
+        got = gpu.resize2d(a, dst, method)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-15 * np.abs(a).max())
+
+
+@pytest.mark.gpu
+def test_device_resident_pyramid_equals_host_pyramid(gpu):
+    """The HBM-resident level loop (device resize, device bounds, device-pointer fits) returns what the numpy resize +
+    host-array solver calls return, with and without a segmentation that drops voxels."""
+    from pyneapple_amd.solvers import HipCurveFitSolver
+
+    rng = np.random.default_rng(3)
+    b = np.linspace(0, 1200, 24)
+    X, Y, Z = 24, 20, 2
+    f1 = 0.2 + 0.1 * rng.random((X, Y, Z))
+    D1 = 0.02 + 0.01 * rng.random((X, Y, Z))
+    D2 = 0.001 + 0.0005 * rng.random((X, Y, Z))
+    img = f1[..., None] * np.exp(-b * D1[..., None]) + (1 - f1[..., None]) * np.exp(-b * D2[..., None])
+    img = img * (1 + 0.01 * rng.standard_normal(img.shape))
+    seg = np.zeros((X, Y, Z), int)
+    seg[4:20, 3:15, :] = 1
+    steps = np.array([[6, 5], [12, 10], [24, 20]])
+    tol = {"f1": 0.5, "D1": 0.5, "D2": 0.5}
+
+    def run(resident, segmentation):
+        solver = HipCurveFitSolver(model=BiExpModel(), max_iter=250, tol=1e-8, p0={"f1": 0.2, "D1": 0.01, "D2": 0.001},
+                                   bounds={"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)})
+        f = HipIDEALFitter(solver, steps, tol, device_resident=resident)
+        f.fit(b, img, segmentation)
+        return f, solver
+
+    for segmentation in (None, seg):
+        fh, sh = run(False, segmentation)
+        fd, sd = run(True, segmentation)
+        assert len(fd.step_params) == 3
+        for a, c in zip(fh.step_params, fd.step_params):
+            assert a.shape == c.shape
+            # same arithmetic up to the summation order inside the resize; the fits amplify 1e-16 to ~1e-9
+            np.testing.assert_allclose(c, a, rtol=1e-6, atol=1e-12)
+        np.testing.assert_array_equal(fd.pixel_indices, fh.pixel_indices)
+        for k in ("f1", "D1", "D2"):
+            np.testing.assert_allclose(fd.fitted_params_[k], fh.fitted_params_[k], rtol=1e-6)
+        np.testing.assert_array_equal(sd.diagnostics_["status"], sh.diagnostics_["status"])
+        assert sd.diagnostics_["pcov"].shape == sh.diagnostics_["pcov"].shape and len(sd.pixel_results_) == len(sh.pixel_results_)
