@@ -53,9 +53,31 @@ except Exception:
             return float(np.nanmean(self.r_squared))
 
 
+def _ss_tot(signals: np.ndarray, workers: int = 8) -> np.ndarray:
+    """sum_i (y_i - mean(y))^2 per row; row blocks on a few threads (numpy releases the GIL) -- 134 M elements for the
+    C3 volume take 0.35 s on one thread."""
+    n = signals.shape[0]
+    out = np.empty(n)
+
+    def block(a, e):
+        blk = signals[a:e]
+        d = blk - blk.mean(axis=1, keepdims=True)
+        np.einsum("ij,ij->i", d, d, out=out[a:e])
+
+    if n < (1 << 16):
+        block(0, n)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+
+    edges = np.linspace(0, n, 4 * workers + 1).astype(np.int64)
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(lambda k: block(int(edges[k]), int(edges[k + 1])), range(len(edges) - 1)))
+    return out
+
+
 def r_squared_from_ss(ss_res: np.ndarray, signals: np.ndarray) -> np.ndarray:
     """1 - SS_res / SS_tot, NaN where the signal is constant (fitters/base.py:179-183)."""
-    ss_tot = np.sum((signals - signals.mean(axis=1, keepdims=True)) ** 2, axis=1)
+    ss_tot = _ss_tot(signals)
     with np.errstate(divide="ignore", invalid="ignore"):
         return np.where(ss_tot > 0, 1.0 - ss_res / ss_tot, np.nan).astype(np.float64)
 
@@ -89,7 +111,10 @@ class HipPixelWiseFitter:
             if segmentation.shape != spatial:
                 raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {spatial}.")
             mask = segmentation != 0
-        pixels = np.ascontiguousarray(image[mask], dtype=np.float64)  # (n_px, N), C order of np.where
+        if segmentation is None:  # every voxel: a view, not a 1 GB fancy-index copy
+            pixels = np.ascontiguousarray(image.reshape(-1, image.shape[-1]), dtype=np.float64)
+        else:
+            pixels = np.ascontiguousarray(image[mask], dtype=np.float64)  # (n_px, N), C order of np.where
         self.pixel_indices = np.argwhere(mask)
         pixel_fixed = None
         if fixed_param_maps is not None:
