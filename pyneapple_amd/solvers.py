@@ -246,7 +246,7 @@ class HipCurveFitSolver(CurveFitBase):
         """Result dict of the batch call -> the reference's solver state (curvefit.py:150-159, 214-244)."""
         popt, pcov, status = res["popt"], res["pcov"], res["status"]
         success = status > 0
-        params_rows = np.ascontiguousarray(popt.T)
+        params_rows = popt.T  # (n_px, n_free) strided view: a record's params is one column of popt, no 168 MB transpose
         self.pixel_results_ = PixelResultsView(
             params_rows, pcov, success,
             lambda i, st=status: None if st[i] > 0 else _CURVEFIT_MESSAGES.get(int(st[i]), "fit failed"))
