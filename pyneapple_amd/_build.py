@@ -17,13 +17,15 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 N_MODELS = 7
+# extra flags for the curve-fit translation units only (experiments: PNX_CURVEFIT_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp")
+CURVEFIT_FLAGS = os.environ.get("PNX_CURVEFIT_FLAGS", "").split()
 
 
 def _units():
     units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", []), ("pnx_sweep.o", "pnx_sweep.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
-        units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}"]))
+        units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}", *CURVEFIT_FLAGS]))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
 
 
