@@ -19,10 +19,11 @@ CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17",
 N_MODELS = 7
 # extra flags for the curve-fit translation units only (experiments: PNX_CURVEFIT_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp")
 CURVEFIT_FLAGS = os.environ.get("PNX_CURVEFIT_FLAGS", "").split()
+NNLS_FLAGS = os.environ.get("PNX_NNLS_FLAGS", "").split()  # e.g. -DPNX_NNLS_GBATCH=8 -DPNX_NNLS_WAVES_PER_SIMD=3 -DPNX_NNLS_LDS_ROWS=56
 
 
 def _units():
-    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", []), ("pnx_sweep.o", "pnx_sweep.hip", []),
+    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_sweep.o", "pnx_sweep.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
         units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}", *CURVEFIT_FLAGS]))

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnx_hip.so")
+LIB_PATH = os.environ.get("PNX_LIB") or os.path.join(_HERE, "libpnx_hip.so")  # PNX_LIB: load another build (kernel-variant experiments)
 
 PNX_MAX_PARAMS = 8
 MEM_HOST, MEM_DEVICE = 0, 1

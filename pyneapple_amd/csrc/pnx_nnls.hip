@@ -36,11 +36,20 @@ namespace pnx {
 
 constexpr int kW = 64;
 constexpr int kSlots = kNnlsMaxBins / kW;  // 4
-constexpr int kLdsRows = 48;               // rows of M kept in LDS (<= 64)
+#ifndef PNX_NNLS_LDS_ROWS
+#define PNX_NNLS_LDS_ROWS 48
+#endif
+#ifndef PNX_NNLS_GBATCH
+#define PNX_NNLS_GBATCH 4
+#endif
+#ifndef PNX_NNLS_WAVES_PER_SIMD
+#define PNX_NNLS_WAVES_PER_SIMD 4
+#endif
+constexpr int kLdsRows = PNX_NNLS_LDS_ROWS;  // rows of M kept in LDS (<= 64)
 constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
 constexpr int kNone = 1 << 30;
-constexpr int kGBatch = 4;  // rows of G in flight per lane in the dual update
+constexpr int kGBatch = PNX_NNLS_GBATCH;  // rows of G in flight per lane in the dual update
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
 struct NnlsArgs {
@@ -209,7 +218,7 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #define STAMP(k) do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(64, 4) nnls_kernel(const NnlsArgs A) {
+__global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const NnlsArgs A) {
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
