@@ -11,10 +11,16 @@
  *   - extern "C", plain pointers and sizes, no C++/torch/numpy types.
  *   - Every function returns 0 on success or a negative pnx_error; the message of the last
  *     error of the calling thread is available through pnx_last_error().
- *   - `mem` says where the *per-voxel* arrays live: PNX_MEM_HOST (library stages H2D/D2H itself,
- *     synchronous) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
+ *   - `mem` says where the *per-voxel* arrays live: PNX_MEM_HOST (pageable host memory; the library
+ *     streams chunks of voxels through device slots on its own streams and helper threads -- copies
+ *     in, kernels and copies out overlap -- and returns when every result is in place; `stream` is
+ *     synchronised on entry) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
  *     enqueues work on `stream` and returns; the caller synchronises).  Small shared inputs
  *     (b-values, shared p0/bounds, basis, regulariser) are ALWAYS host pointers.
+ *   - Thread safety: every entry point may be called from several host threads (e.g. one per
+ *     device).  An NNLS plan owns device scratch that serves one solve at a time: host-mode solves
+ *     on one plan serialise internally, device-mode solves on one plan must be enqueued on ONE
+ *     stream (or be ordered by the caller).
  *   - The caller allocates all outputs.  The library owns only device scratch.
  *   - Per-voxel numerical failure never produces an error code: it is reported in `status[]`
  *     with the reference's sentinel outputs (curvefit.py:308-317, nnls_solver.py:201-210).
