@@ -27,7 +27,14 @@ namespace pnx {
 constexpr int kWave = 64;
 constexpr int kMaxB = 128;
 constexpr int kMaxP = 8;
-constexpr int kRowBlk = 8;          // rows merged into the QR factor per Householder block step
+// rows merged into the QR factor per Householder block step: the block is RB x (N + 1) doubles of registers.  Measured
+// (1 Mi voxels, profiles/model_probe.py): N = 3: 321 (RB 8) vs 288 (RB 4) M voxels/s; N = 5: 72.6 vs 75.8; N = 6: 46-49 vs 58
+// (RB 8 spills ~500 B per lane there, RB 4 none).  PNX_ROW_BLK overrides for experiments.
+#ifdef PNX_ROW_BLK
+template <int N> constexpr int row_blk() { return PNX_ROW_BLK; }
+#else
+template <int N> constexpr int row_blk() { return N >= 5 ? 4 : 8; }
+#endif
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kSqrtEps = 1.4901161193847656e-08;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -583,7 +590,10 @@ template <int N> struct Park {
 // Register diet: bounds stay in SGPRs unless they are per voxel (PV); R (for the covariance) and the
 // singular vectors V are parked in LDS; nothing produced by the pass stays live across the next pass.
 template <int MODEL, int N, bool FD, bool PV, bool T1>
-__global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
+#ifndef PNX_CF_WAVES_PER_SIMD
+#define PNX_CF_WAVES_PER_SIMD 1
+#endif
+__global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(const CurvefitArgs A) {
     using M = Model<MODEL>;
     using PK = Park<N>;
     constexpr int NALL = M::NALL;            // parameters of the diffusion model
@@ -762,6 +772,7 @@ __global__ void __launch_bounds__(256) curvefit_kernel(const CurvefitArgs A) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) Rn[i][j] = 0;
             }
+            constexpr int kRowBlk = row_blk<N>();
             for (int i0 = 0; i0 < n_b; i0 += kRowBlk) {
                 double blk[kRowBlk][N + 1];
 #pragma unroll
