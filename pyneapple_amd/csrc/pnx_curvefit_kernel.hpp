@@ -13,11 +13,14 @@
 //     next voxel from a global atomic counter instead of idling until the slowest voxel of its wave is done.
 //     Every lane leaves the loop as soon as the queue is empty, so the grid always drains.
 //   * ONE FUSED "ROW PASS" per trial point: residual, cost, Jacobian row (2-point FD exactly as
-//     scipy/_numdiff.py:584-625, or analytic), J^T f and a Householder QR of J accumulated 8 rows at a time.
+//     scipy/_numdiff.py:584-625, or analytic), J^T f and a Householder QR of J accumulated row_blk<N>() rows at a time.
 //     The Jacobian never exists in memory; TRF's SVD of the (m+n) x n augmented matrix is taken from the
 //     n x n triangular factor (QR then one-sided Jacobi), which is as accurate as LAPACK's SVD of J_aug.
 //   * The Jacobian at the trial point is computed speculatively together with f(x_new): an accepted step
 //     (the common case) then needs no second pass.
+//   * ASYNCHRONOUS REFILL: a lane that has written its results claims the next voxel and issues global->LDS DMA loads
+//     (global_load_lds) of its signal row; they land while the other lanes run the heavy phases and are collected by
+//     one s_waitcnt vmcnt(0) in front of the next row pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -589,10 +592,10 @@ template <int N> struct Park {
 //   C        trust-region step -> next x_new.
 // Register diet: bounds stay in SGPRs unless they are per voxel (PV); R (for the covariance) and the
 // singular vectors V are parked in LDS; nothing produced by the pass stays live across the next pass.
-template <int MODEL, int N, bool FD, bool PV, bool T1>
 #ifndef PNX_CF_WAVES_PER_SIMD
-#define PNX_CF_WAVES_PER_SIMD 1
+#define PNX_CF_WAVES_PER_SIMD 1  // 2 was measured at 47-60 M voxels/s (spills, and the LDS park of 8 waves does not fit for n_b = 32)
 #endif
+template <int MODEL, int N, bool FD, bool PV, bool T1>
 __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(const CurvefitArgs A) {
     using M = Model<MODEL>;
     using PK = Park<N>;
