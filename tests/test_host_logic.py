@@ -154,3 +154,49 @@ def test_split_covers_range_without_overlap():
         parts = _split(n, p)
         assert parts[0][0] == 0 and parts[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(parts[:-1], parts[1:]))
+
+
+def test_solver_n_gpus_sharding_reassembles_rows(monkeypatch):
+    """`n_gpus > 1` shards voxels over devices inside one process: every device gets a contiguous row range of the
+    signal, of per-voxel p0 / bounds and of the fixed maps, and the results come back in voxel order.  The device call
+    is replaced by a recorder here (the kernels are covered by the gpu tests; an 8-GPU node is the driver's)."""
+    import numpy as np
+
+    from pyneapple_amd import api, solvers
+    from pyneapple_amd.models import BiExpModel
+
+    calls = []
+
+    def fake_curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, device=0, **kw):
+        n_vox = y.shape[0]
+        n = p0.shape[0]
+        calls.append((device, n_vox, p0.shape, None if fixed_vals is None else np.shape(fixed_vals)))
+        # encode (device, row content) so that the re-assembly can be checked
+        popt = np.tile(y[:, 0][None, :], (n, 1)) + (p0 if p0.ndim == 2 else p0[:, None]) * 0
+        if fixed_vals is not None and np.ndim(fixed_vals) == 2:
+            popt[0] = fixed_vals[0]
+        return dict(popt=popt, pcov=np.zeros((n_vox, n, n)) + device, status=np.ones(n_vox, np.int8),
+                    nfev=np.full(n_vox, device, np.int32), cost=y[:, 1].copy())
+
+    monkeypatch.setattr(api, "curvefit", fake_curvefit)
+    n_vox = 1003
+    b = np.linspace(0, 1000, 8)
+    y = np.arange(n_vox * 8, dtype=float).reshape(n_vox, 8)
+    s = solvers.HipCurveFitSolver(model=BiExpModel(), max_iter=250, tol=1e-8, p0={"f1": 0.2, "D1": 0.01, "D2": 0.001},
+                                  bounds={"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}, n_gpus=4, device=2)
+    d1 = np.linspace(0.005, 0.05, n_vox)
+    s.fit(b, y, pixel_fixed_params={"D1": d1})
+    assert [c[0] for c in calls] == [2, 3, 4, 5] and sum(c[1] for c in calls) == n_vox
+    assert all(c[3] == (1, c[1]) for c in calls)  # the fixed map was sliced with the rows
+    np.testing.assert_array_equal(s.params_["f1"], d1)            # row 0 carried the fixed map through
+    np.testing.assert_array_equal(s.params_["D2"], y[:, 0])       # voxel order preserved
+    np.testing.assert_array_equal(s.diagnostics_["cost"], y[:, 1])
+    assert sorted(set(s.diagnostics_["nfev"].tolist())) == [2, 3, 4, 5]
+    assert s.diagnostics_["pcov"].shape == (n_vox, 2, 2)
+    # per-voxel p0 / bounds arrays are sliced the same way
+    calls.clear()
+    p0 = np.tile(np.array([0.2, 0.01, 0.001])[:, None], (1, n_vox))
+    lo = np.tile(np.array([0.0, 1e-3, 1e-5])[:, None], (1, n_vox))
+    hi = np.tile(np.array([1.0, 0.1, 5e-3])[:, None], (1, n_vox))
+    s.fit(b, y, p0=p0, bounds=(lo, hi))
+    assert all(c[2] == (3, c[1]) for c in calls) and len(calls) == 4
