@@ -370,7 +370,14 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "nnls_kernel", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach2 / HBM_PEAK_GBS, "traffic": nnls_traffic(leg2.n_vox) if not args.voxels else None,
                             "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel, "kernel_ms_avg": k2avg * 1e3,
-                            "note": "active-set loop is latency / VALU-issue / L2-bandwidth bound (DESIGN.md 4.3)"}}
+                            "note": "active-set loop is VALU-issue bound: 4 waves per SIMD keep the issue slots 73 % busy, 24 % of the instructions are fp64 arithmetic (DESIGN.md 4.3)"}}
+        fl2 = pmc_flops("nnls_kernel")
+        if fl2:  # the active-set kernel is VALU-issue bound (73 % of the SIMD issue slots, a quarter of them fp64)
+            tf2 = fl2["fp64_flop_per_voxel_issued"] * leg2.n_vox / k2avg / 1e12
+            sec["roofline"]["valu_f64"] = {"achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf2 / FP64_PEAK_TFLOPS,
+                                           "fp64_flop_per_voxel_issued": fl2["fp64_flop_per_voxel_issued"],
+                                           "fp64_share_of_valu_instructions": fl2["fp64_share_of_valu_instructions"],
+                                           "lane_utilisation": fl2["lane_utilisation"], "source": "profiles/r01_g_flops.json"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec

@@ -286,29 +286,33 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
             // ---- dual w = A^T y - G[:,P] x_P on the zero set: p rows of G (L2 resident), kGBatch in flight
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
-            for (int pos0 = 0; pos0 < p; pos0 += kGBatch) {
-                double2 ga[kGBatch], gb[kGBatch];
-                double xs[kGBatch];
+            // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
+            // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
 #pragma unroll
-                for (int u = 0; u < kGBatch; ++u) {
-                    const int pos = pos0 + u < p ? pos0 + u : p - 1;
-                    const int sl = pos >> 6, ll_ = pos & 63;
-                    const int col = sl == 0 ? __builtin_amdgcn_readlane(pidx[0], ll_)
-                                  : sl == 1 ? __builtin_amdgcn_readlane(pidx[1], ll_)
-                                  : sl == 2 ? __builtin_amdgcn_readlane(pidx[2], ll_)
-                                            : __builtin_amdgcn_readlane(pidx[3], ll_);
-                    const double xv = sl == 0 ? rl(x[0], ll_) : sl == 1 ? rl(x[1], ll_) : sl == 2 ? rl(x[2], ll_) : rl(x[3], ll_);
-                    xs[u] = pos0 + u < p ? xv : 0.0;
-                    const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
-                    ga[u] = *reinterpret_cast<const double2 *>(gc);
-                    gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
-                }
+            for (int sl = 0; sl < kSlots; ++sl) {
+                if (p <= sl * kW) break;  // wave-uniform
+                const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
+                for (int l0 = 0; l0 < cnt; l0 += kGBatch) {
+                    double2 ga[kGBatch], gb[kGBatch];
+                    double xs[kGBatch];
 #pragma unroll
-                for (int u = 0; u < kGBatch; ++u) {
-                    w[0] -= ga[u].x * xs[u];
-                    w[1] -= ga[u].y * xs[u];
-                    w[2] -= gb[u].x * xs[u];
-                    w[3] -= gb[u].y * xs[u];
+                    for (int u = 0; u < kGBatch; ++u) {
+                        const bool on = l0 + u < cnt;
+                        const int ll_ = on ? l0 + u : cnt - 1;
+                        const int col = __builtin_amdgcn_readlane(pidx[sl], ll_);
+                        const double xv = rl(x[sl], ll_);
+                        xs[u] = on ? xv : 0.0;
+                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
+                        ga[u] = *reinterpret_cast<const double2 *>(gc);
+                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        w[0] -= ga[u].x * xs[u];
+                        w[1] -= ga[u].y * xs[u];
+                        w[2] -= gb[u].x * xs[u];
+                        w[3] -= gb[u].y * xs[u];
+                    }
                 }
             }
 #pragma unroll
