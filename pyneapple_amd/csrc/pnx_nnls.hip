@@ -292,7 +292,27 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
             for (int sl = 0; sl < kSlots; ++sl) {
                 if (p <= sl * kW) break;  // wave-uniform
                 const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
-                for (int l0 = 0; l0 < cnt; l0 += kGBatch) {
+                int l0 = 0;
+                for (; l0 + kGBatch <= cnt; l0 += kGBatch) {  // full batches: no clamping, no masking
+                    double2 ga[kGBatch], gb[kGBatch];
+                    double xs[kGBatch];
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        const int col = __builtin_amdgcn_readlane(pidx[sl], l0 + u);
+                        xs[u] = rl(x[sl], l0 + u);
+                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
+                        ga[u] = *reinterpret_cast<const double2 *>(gc);
+                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        w[0] -= ga[u].x * xs[u];
+                        w[1] -= ga[u].y * xs[u];
+                        w[2] -= gb[u].x * xs[u];
+                        w[3] -= gb[u].y * xs[u];
+                    }
+                }
+                if (l0 < cnt) {  // ragged last batch
                     double2 ga[kGBatch], gb[kGBatch];
                     double xs[kGBatch];
 #pragma unroll
@@ -359,7 +379,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     for (int k = 0; k < plim; ++k) {
                         const double gk = rl(g[0], k);
                         const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
-                        l[0] += (mine && lane >= k) ? m0 * gk : 0.0;
+                        l[0] = fma(m0, (mine && lane >= k) ? gk : 0.0, l[0]);
                     }
                 }
                 // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
