@@ -375,12 +375,24 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     const int plim = p < kLdsRows ? p : kLdsRows;
                     const bool mine = lane < plim;
                     const double *row0 = Mlds + tri(mine ? lane : 0);
-#pragma unroll 8
-                    for (int k = 0; k < plim; ++k) {
+                    // unrolled by hand (the compiler does not unroll loops around v_readlane): four LDS reads in flight,
+                    // two accumulators, a quarter of the loop control
+                    double acc0 = 0, acc1 = 0;
+                    int k = 0;
+                    for (; k + 4 <= plim; k += 4) {
+                        const double g0 = rl(g[0], k), g1 = rl(g[0], k + 1), g2 = rl(g[0], k + 2), g3 = rl(g[0], k + 3);
+                        const double m0 = row0[k], m1 = row0[k + 1], m2 = row0[k + 2], m3 = row0[k + 3];
+                        acc0 = fma(m0, (mine && lane >= k) ? g0 : 0.0, acc0);
+                        acc1 = fma(m1, (mine && lane >= k + 1) ? g1 : 0.0, acc1);
+                        acc0 = fma(m2, (mine && lane >= k + 2) ? g2 : 0.0, acc0);
+                        acc1 = fma(m3, (mine && lane >= k + 3) ? g3 : 0.0, acc1);
+                    }
+                    for (; k < plim; ++k) {
                         const double gk = rl(g[0], k);
                         const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
-                        l[0] = fma(m0, (mine && lane >= k) ? gk : 0.0, l[0]);
+                        acc0 = fma(m0, (mine && lane >= k) ? gk : 0.0, acc0);
                     }
+                    l[0] = acc0 + acc1;
                 }
                 // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
                 for_pos<2>(kLdsRows, p, [&](int i, auto S) {
