@@ -140,6 +140,21 @@ template <int UNROLL, class F> __device__ inline void for_pos(int lo, int hi, F 
     if (hi > 2 * kW) pos_range<2, UNROLL>(lo, hi, f);
     if (hi > 3 * kW) pos_range<3, UNROLL>(lo, hi, f);
 }
+// the same in groups of four: f4(i, SlotTag<S>) covers positions i .. i + 3 (all in slot S), f1 the ragged rest.  Loops
+// around v_readlane / DPP are never unrolled by the compiler, so "several rows in flight" has to be spelled out.
+template <int S, class F4, class F1> __device__ inline void pos_range4(int lo, int hi, F4 &&f4, F1 &&f1) {
+    const int a = lo > kW * S ? lo : kW * S;
+    const int b = hi < kW * S + kW ? hi : kW * S + kW;
+    int i = a;
+    for (; i + 4 <= b; i += 4) f4(i, SlotTag<S>{});
+    for (; i < b; ++i) f1(i, SlotTag<S>{});
+}
+template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4 &&f4, F1 &&f1) {
+    pos_range4<0>(lo, hi, f4, f1);
+    if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
+    if (hi > 2 * kW) pos_range4<2>(lo, hi, f4, f1);
+    if (hi > 3 * kW) pos_range4<3>(lo, hi, f4, f1);
+}
 // write v at (uniform) position pos
 __device__ inline void put(double (&a)[kSlots], int pos, double v, int lane) {
     if (lane == (pos & 63)) {
@@ -195,7 +210,8 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
         oa[0] += a * m;
         if (TWO) ob[0] += b * m;
     }
-    for_pos<4>(kLdsRows, p, [&](int i, auto S) {
+    // overflow rows (global scratch): four rows' loads are issued before any of them is consumed
+    auto one = [&](int i, auto S) {
         constexpr int si = decltype(S)::value;
         const double a = rl(va[si], i & 63);
         const double b = TWO ? rl(vb[si], i & 63) : 0.0;
@@ -209,7 +225,32 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
             oa[s] += a * m;
             if (TWO) ob[s] += b * m;
         }
-    });
+    };
+    auto four = [&](int i, auto S) {
+        constexpr int si = decltype(S)::value;
+        double m[4][si + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double *row = Mg + (tri(i + r) - kLdsTri);
+#pragma unroll
+            for (int s = 0; s <= si; ++s) {
+                const int k = lane + kW * s;
+                m[r][s] = row[k <= i + r ? k : 0];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double a = rl(va[si], (i + r) & 63);
+            const double b = TWO ? rl(vb[si], (i + r) & 63) : 0.0;
+#pragma unroll
+            for (int s = 0; s <= si; ++s) {
+                const double mm = (lane + kW * s <= i + r) ? m[r][s] : 0.0;
+                oa[s] += a * mm;
+                if (TWO) ob[s] += b * mm;
+            }
+        }
+    };
+    for_pos4(kLdsRows, p, four, one);
 }
 
 #ifdef PNX_NNLS_STAMP
@@ -395,20 +436,48 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     l[0] = acc0 + acc1;
                 }
                 // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
-                for_pos<2>(kLdsRows, p, [&](int i, auto S) {
-                    constexpr int si = decltype(S)::value;
-                    const double *row = Mg + (tri(i) - kLdsTri);
-                    double part = 0;
+                {
+                    auto one = [&](int i, auto S) {
+                        constexpr int si = decltype(S)::value;
+                        const double *row = Mg + (tri(i) - kLdsTri);
+                        double part = 0;
 #pragma unroll
-                    for (int s = 0; s <= si; ++s) {
-                        const int k = lane + kW * s;
-                        const bool on = k <= i;
-                        const double m0 = row[on ? k : 0];
-                        part += on ? m0 * g[s] : 0.0;
-                    }
-                    const double li = wave_sum(part);
-                    if (lane == (i & 63)) l[si] = li;
-                });
+                        for (int s = 0; s <= si; ++s) {
+                            const int k = lane + kW * s;
+                            const bool on = k <= i;
+                            const double m0 = row[on ? k : 0];
+                            part += on ? m0 * g[s] : 0.0;
+                        }
+                        const double li = wave_sum(part);
+                        if (lane == (i & 63)) l[si] = li;
+                    };
+                    auto four = [&](int i, auto S) {  // four rows in flight, then four independent reductions
+                        constexpr int si = decltype(S)::value;
+                        double m[4][si + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double *row = Mg + (tri(i + r) - kLdsTri);
+#pragma unroll
+                            for (int s = 0; s <= si; ++s) {
+                                const int k = lane + kW * s;
+                                m[r][s] = row[k <= i + r ? k : 0];
+                            }
+                        }
+                        double part[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            part[r] = 0;
+#pragma unroll
+                            for (int s = 0; s <= si; ++s) part[r] += (lane + kW * s <= i + r) ? m[r][s] * g[s] : 0.0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double li = wave_sum(part[r]);
+                            if (lane == ((i + r) & 63)) l[si] = li;
+                        }
+                    };
+                    for_pos4(kLdsRows, p, four, one);
+                }
                 double ll = 0, lq = 0;
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
