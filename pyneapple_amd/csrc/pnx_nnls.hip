@@ -264,7 +264,8 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M
+    extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M, then bc[64]
+    double *bc = Mlds + kLdsTri;      // broadcast buffer: position-indexed values of slot 0, read with a uniform address
     const int lane = threadIdx.x;
     double *Mg = A.Mglob + (size_t)blockIdx.x * kGlobTri;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
@@ -329,6 +330,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
             for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
             // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
             // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
+            bc[lane] = x[0];  // the kernel is VALU-issue bound: x_pos comes back through an LDS broadcast read, not 2 readlanes
 #pragma unroll
             for (int sl = 0; sl < kSlots; ++sl) {
                 if (p <= sl * kW) break;  // wave-uniform
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
                         const int col = __builtin_amdgcn_readlane(pidx[sl], l0 + u);
-                        xs[u] = rl(x[sl], l0 + u);
+                        xs[u] = sl == 0 ? bc[l0 + u] : rl(x[sl], l0 + u);
                         const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
                         ga[u] = *reinterpret_cast<const double2 *>(gc);
                         gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
@@ -828,7 +830,8 @@ __global__ void basis_kernel(const double *b, const double *bins, int nm, int n,
         if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-static size_t nnls_lds_bytes() { return sizeof(double) * kLdsTri; }
+// rows 0..kLdsRows-1 of M plus a 64-entry broadcast buffer (a uniform-address ds_read_b64 replaces two v_readlane)
+static size_t nnls_lds_bytes() { return sizeof(double) * (kLdsTri + kW); }
 
 int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                    int device, int cus) {
