@@ -200,9 +200,11 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
     }
     const int p_lds = p < kLdsRows ? p : kLdsRows;
     // branch-free body (clamped address, masked product) so that the unrolled steps keep their LDS reads in flight
-#pragma unroll 8
+    extern __shared__ double dyn_lds[];  // the kernel's dynamic LDS (same base as Mlds): rows of M, then bc[64]
+    double *bc = dyn_lds + kLdsTri;
+    bc[lane] = va[0];  // broadcast reads (one LDS instruction) instead of two v_readlane per value: the kernel is VALU bound
     for (int i = 0; i < p_lds; ++i) {
-        const double a = rl(va[0], i);
+        const double a = bc[i];
         const double b = TWO ? rl(vb[0], i) : 0.0;
         const bool on = lane <= i;
         const double m0 = Mlds[tri(i) + (on ? lane : 0)];
@@ -422,8 +424,9 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     // two accumulators, a quarter of the loop control
                     double acc0 = 0, acc1 = 0;
                     int k = 0;
+                    bc[lane] = g[0];
                     for (; k + 4 <= plim; k += 4) {
-                        const double g0 = rl(g[0], k), g1 = rl(g[0], k + 1), g2 = rl(g[0], k + 2), g3 = rl(g[0], k + 3);
+                        const double g0 = bc[k], g1 = bc[k + 1], g2 = bc[k + 2], g3 = bc[k + 3];
                         const double m0 = row0[k], m1 = row0[k + 1], m2 = row0[k + 2], m3 = row0[k + 3];
                         acc0 = fma(m0, (mine && lane >= k) ? g0 : 0.0, acc0);
                         acc1 = fma(m1, (mine && lane >= k + 1) ? g1 : 0.0, acc1);
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                         acc1 = fma(m3, (mine && lane >= k + 3) ? g3 : 0.0, acc1);
                     }
                     for (; k < plim; ++k) {
-                        const double gk = rl(g[0], k);
+                        const double gk = bc[k];
                         const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
                         acc0 = fma(m0, (mine && lane >= k) ? gk : 0.0, acc0);
                     }
