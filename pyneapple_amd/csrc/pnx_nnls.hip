@@ -428,17 +428,17 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     for (; k + 4 <= plim; k += 4) {
                         const double g0 = bc[k], g1 = bc[k + 1], g2 = bc[k + 2], g3 = bc[k + 3];
                         const double m0 = row0[k], m1 = row0[k + 1], m2 = row0[k + 2], m3 = row0[k + 3];
-                        acc0 = fma(m0, (mine && lane >= k) ? g0 : 0.0, acc0);
-                        acc1 = fma(m1, (mine && lane >= k + 1) ? g1 : 0.0, acc1);
-                        acc0 = fma(m2, (mine && lane >= k + 2) ? g2 : 0.0, acc0);
-                        acc1 = fma(m3, (mine && lane >= k + 3) ? g3 : 0.0, acc1);
+                        if (lane >= k) acc0 = fma(m0, g0, acc0);       // exec-masked (scalar unit) instead of 2 v_cndmask;
+                        if (lane >= k + 1) acc1 = fma(m1, g1, acc1);   // lanes >= plim accumulate garbage they never use
+                        if (lane >= k + 2) acc0 = fma(m2, g2, acc0);
+                        if (lane >= k + 3) acc1 = fma(m3, g3, acc1);
                     }
                     for (; k < plim; ++k) {
                         const double gk = bc[k];
                         const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
-                        acc0 = fma(m0, (mine && lane >= k) ? gk : 0.0, acc0);
+                        if (lane >= k) acc0 = fma(m0, gk, acc0);
                     }
-                    l[0] = acc0 + acc1;
+                    l[0] = mine ? acc0 + acc1 : 0.0;
                 }
                 // overflow rows: contiguous row read (lanes over k), DPP reduction, result to the owner of i
                 {
