@@ -206,9 +206,10 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
     for (int i = 0; i < p_lds; ++i) {
         const double a = bc[i];
         const double b = TWO ? rl(vb[0], i) : 0.0;
-        const bool on = lane <= i;
-        const double m0 = Mlds[tri(i) + (on ? lane : 0)];
-        const double m = on ? m0 : 0.0;
+        // lanes beyond the row read on into the following rows / the broadcast buffer (inside the allocation: tri(47) + 63 <
+        // kLdsTri + 64); their product is masked
+        const double m0 = Mlds[tri(i) + lane];
+        const double m = (lane <= i) ? m0 : 0.0;
         oa[0] += a * m;
         if (TWO) ob[0] += b * m;
     }
