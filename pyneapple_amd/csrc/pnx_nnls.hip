@@ -223,7 +223,7 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
         for (int s = 0; s <= si; ++s) {
             const int k = lane + kW * s;
             const bool on = k <= i;
-            const double m0 = row[on ? k : 0];
+            const double m0 = row[k];  // past the row end: the following rows of this wave's slab (masked below)
             const double m = on ? m0 : 0.0;
             oa[s] += a * m;
             if (TWO) ob[s] += b * m;
@@ -238,7 +238,7 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #pragma unroll
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
-                m[r][s] = row[k <= i + r ? k : 0];
+                m[r][s] = row[k];  // past the row end: the following rows of this wave's slab (masked below)
             }
         }
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                         for (int s = 0; s <= si; ++s) {
                             const int k = lane + kW * s;
                             const bool on = k <= i;
-                            const double m0 = row[on ? k : 0];
+                            const double m0 = row[k];  // past the row end: the following rows of this wave's slab (masked below)
                             part += on ? m0 * g[s] : 0.0;
                         }
                         const double li = wave_sum(part);
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
 #pragma unroll
                             for (int s = 0; s <= si; ++s) {
                                 const int k = lane + kW * s;
-                                m[r][s] = row[k <= i + r ? k : 0];
+                                m[r][s] = row[k];  // past the row end: the following rows of this wave's slab (masked below)
                             }
                         }
                         double part[4];
