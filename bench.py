@@ -182,11 +182,11 @@ def timed(leg, steps, warmup, world, dist, torch):
 
 
 def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_i_traffic.json;
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_j_traffic.json;
     FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is).  bench.py cannot run rocprofv3 around itself,
     so the figure is the one measured on this kernel and this full-size workload when the profile was taken."""
     try:
-        with open(os.path.join(HERE, "profiles", "r01_i_traffic.json")) as f:
+        with open(os.path.join(HERE, "profiles", "r01_j_traffic.json")) as f:
             t = json.load(f)
         for name, v in t.items():
             if kernel_prefix in name:
@@ -201,9 +201,9 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (MI355X_MICROAR
 
 def pmc_flops(kernel_prefix: str):
     """fp64 flop per voxel ISSUED by the kernel (64 lanes per fp64 VALU instruction, FMA = 2), from the committed
-    PMC pass (profiles/r01_i_pmc_*.txt -> profiles/r01_i_flops.json)."""
+    PMC pass (profiles/r01_j_pmc_*.txt -> profiles/r01_j_flops.json)."""
     try:
-        with open(os.path.join(HERE, "profiles", "r01_i_flops.json")) as f:
+        with open(os.path.join(HERE, "profiles", "r01_j_flops.json")) as f:
             t = json.load(f)
         for name, v in t.items():
             if kernel_prefix in name:
@@ -354,7 +354,7 @@ def main():
         tf = fl["fp64_flop_per_voxel_issued"] * leg.n_vox / k_avg / 1e12
         out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                                        "fp64_flop_per_voxel_issued": fl["fp64_flop_per_voxel_issued"],
-                                       "lane_utilisation": fl["lane_utilisation"], "source": "profiles/r01_i_flops.json"}
+                                       "lane_utilisation": fl["lane_utilisation"], "source": "profiles/r01_j_flops.json"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = leg.cpu_baseline()
     if args.workload == "triexp" and not args.no_secondary:
@@ -377,7 +377,7 @@ def main():
             sec["roofline"]["valu_f64"] = {"achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf2 / FP64_PEAK_TFLOPS,
                                            "fp64_flop_per_voxel_issued": fl2["fp64_flop_per_voxel_issued"],
                                            "fp64_share_of_valu_instructions": fl2["fp64_share_of_valu_instructions"],
-                                           "lane_utilisation": fl2["lane_utilisation"], "source": "profiles/r01_i_flops.json"}
+                                           "lane_utilisation": fl2["lane_utilisation"], "source": "profiles/r01_j_flops.json"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec
