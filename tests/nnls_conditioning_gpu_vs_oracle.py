@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """NNLS parity against the oracle over the conditioning of the problem: measurements 32 / 16 / 8, regulariser order 1-3,
-mu 0.0005 ... 0.02 (250 bins, 2000 noisy triexp voxels each).  Run from the repo root on a GPU box."""
+mu 0.0005 ... 0.02 (250 bins, 2000 noisy triexp voxels each).  Not collected by pytest: run it by hand on a GPU box
+(it lives under tests/ because only tests may use the oracle)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import pnx_oracle as oracle
 from pyneapple_amd import api, synth
