@@ -5,19 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one batched fit through the C ABI, device-pointer mode) over one
-synthetic volume that is already resident in HBM.  Default workload: BASELINE.json configs[2]
-(triexp bounded TRF, 256x256x64 voxels x 32 b-values), computed in fp64 with SciPy's 2-point finite
-difference Jacobian and with the covariance output, i.e. exactly what the reference's pixelwise fitter
-asks of its solver.  Voxels shard with no collective: every rank fits its own volume (weak scaling);
-value = (voxels of all ranks) / (max over ranks of the timed region).
-Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (one batched fit through the C ABI, device-pointer mode) over ONE seed-fixed
+synthetic volume that is already resident in HBM.  Default workload: BASELINE.json configs[2] (triexp bounded TRF,
+256x256x64 voxels x 32 b-values), computed in fp64 with SciPy's 2-point finite difference Jacobian and with the
+covariance output, i.e. exactly what the reference's pixelwise fitter asks of its solver.
+
+Multi-GPU (north star: "voxels shard embarrassingly across the GPUs of one node"): the ONE volume is split into
+contiguous row ranges, rank r fits sharding.shard_range(n_vox, r, N) -- strong scaling, no data-path collective;
+RCCL only carries the barrier and the MAX-reduce of the timed region.  value = voxels of the whole volume x steps /
+(max over ranks of the timed region).  `--gpus N` without a torchrun environment starts the N ranks itself: fresh
+child processes, spawned before anything in this process touches the GPU.  Rank 0 prints ONE JSON line.
+
+`value` is the device-resident rate (inputs in HBM when the timed region starts, as the bench contract asks);
+`host_mode` (N = 1) is the PCIe-inclusive rate of the same work through PNX_MEM_HOST -- numpy arrays in, numpy arrays
+out, what the reference's fitter hands its solver (fitters/pixelwise.py:91-96).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,7 +35,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (half the 157.3 TF fp32 rate of MI355X_MICROARCH.md)
 METRIC = "voxels/sec (pixelwise triexp LM & 250-bin NNLS) at 1/2/4/8 MI355X"
+CURVEFIT_C3_KERNEL = "curvefit_kernel<4, 5, true, false, false>"  # rocprofv3's name of the C3 instantiation
 
 
 def host_cores() -> int:
@@ -39,7 +49,7 @@ def host_cores() -> int:
     return int(os.environ.get("PNX_CPU_THREADS", min(n, 16)))
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -49,12 +59,50 @@ def parse():
     ap.add_argument("--no-pcov", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the NNLS leg that is reported beside triexp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--voxels", type=int, default=0, help="override voxels per GPU (debug; marks the line invalid)")
-    return ap.parse_args()
+    ap.add_argument("--no-host-mode", action="store_true", help="skip the PCIe-inclusive host-pointer legs")
+    ap.add_argument("--voxels", type=int, default=0, help="override the voxels of the volume (debug; marks the line invalid)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="every rank prints its rank / world / shard as JSON and exits without touching the GPU")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` outside torchrun starts N fresh ranks before this process touches the GPU
+def launch(args, argv) -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 or args.launch_check else subprocess.DEVNULL))
+    rc = 0
+    outs = []
+    for p in procs:
+        out, _ = p.communicate()
+        outs.append(out.decode() if out else "")
+        rc = rc or p.returncode
+    sys.stdout.write("".join(outs) if args.launch_check else outs[0])
+    sys.stdout.flush()
+    return rc
+
+
+def volume_rows(workload, args, rank, world):
+    """(n_vox of the whole volume, [start, stop) of this rank): contiguous row ranges of ONE volume."""
+    from pyneapple_amd import synth
+    from pyneapple_amd.sharding import shard_range
+
+    n_vox = args.voxels or int(np.prod(synth.WORKLOADS[workload][2]))
+    return n_vox, shard_range(n_vox, rank, world)
 
 
 class CurvefitLeg:
-    def __init__(self, workload, device, jac, want_pcov, n_vox_override=0, seed=0):
+    def __init__(self, workload, device, jac, want_pcov, n_vox_total, rows):
         import torch
         from pyneapple_amd import api, synth
 
@@ -62,11 +110,13 @@ class CurvefitLeg:
         self.api = api
         model, n_b, shape = synth.WORKLOADS[workload]
         self.model, self.n_b, self.shape = model, n_b, shape
-        self.n_vox = n_vox_override or int(np.prod(shape))
+        self.n_vox_total, self.rows = n_vox_total, rows
+        self.n_vox = rows[1] - rows[0]
         self.names, self.p0, self.lo, self.hi = synth.shared_arrays(model)
         n = len(self.names)
         self.n = n
-        self.b, self.y = synth.make_torch(model, self.n_vox, n_b, device, sigma=0.01, seed=synth.SEED + seed)
+        self.jac, self.want_pcov = jac, want_pcov
+        self.b, self.y = synth.make_torch_rows(model, rows[0], rows[1], n_b, device, sigma=0.01)
         self.opts = api.make_opts(model, n_b, max_nfev=250, ftol=1e-8, jac=jac)
         self.popt = torch.empty((n, self.n_vox), dtype=torch.float64, device=device)
         self.pcov = torch.empty((self.n_vox, n, n), dtype=torch.float64, device=device) if want_pcov else None
@@ -88,7 +138,24 @@ class CurvefitLeg:
         ok = (self.status > 0).double().mean().item()
         return {"converged_frac": ok, "mean_nfev": self.nfev.double().mean().item()}
 
-    def cpu_baseline(self, seconds_target=15.0):
+    def host_mode(self, reps=2):
+        """The same fit through PNX_MEM_HOST: numpy signal in, numpy popt / pcov / status / nfev / cost out (PCIe inclusive)."""
+        y = self.y.cpu().numpy()
+        kw = dict(max_nfev=250, ftol=1e-8, jac=self.jac, want_pcov=self.want_pcov, device=self.device.index)
+        r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)  # warm-up (slots, first-touch)
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)
+            ts.append(time.perf_counter() - t)
+        dt = float(np.mean(ts))
+        d2h = sum(a.nbytes for a in r.values() if a is not None)
+        same = bool((self.torch.from_numpy(r["popt"]).to(self.popt.device) == self.popt).all().item())
+        return {"workload": "same volume, host (numpy) arrays in and out through PNX_MEM_HOST", "value": self.n_vox / dt,
+                "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes), "d2h_bytes": int(d2h),
+                "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps, "equals_device_resident_result": same}
+
+    def cpu_baseline(self):
         """The oracle (C restatement of SciPy TRF) on the host cores, bounded sample of the same workload."""
         from oracle import pnx_oracle as O
         from pyneapple_amd import synth
@@ -102,25 +169,26 @@ class CurvefitLeg:
                        n_threads=cores)
         dt = time.perf_counter() - t
         return {"value": n / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-                "sample": f"{n} voxels of the same synthetic {self.model} volume, oracle/pnx_oracle_trf.c, "
+                "sample": f"{n} voxels of the same synthetic {self.model} distribution, oracle/pnx_oracle_trf.c, "
                           f"OpenMP over voxels, {dt:.2f} s", "converged_frac": float((r['status'] > 0).mean())}
 
 
 class NnlsLeg:
-    def __init__(self, device, n_vox_override=0, seed=0):
+    def __init__(self, device, n_vox_total, rows):
         import torch
         from pyneapple_amd import api, synth
 
         self.torch = torch
+        self.api = api
         _, n_b, shape = synth.WORKLOADS["nnls"]
         self.n_b = n_b
-        self.n_vox = n_vox_override or int(np.prod(shape))
+        self.n_vox_total, self.rows = n_vox_total, rows
+        self.n_vox = rows[1] - rows[0]
         cfg = synth.NNLS_CFG
         self.cfg = cfg
         self.bins, self.basis, self.reg = synth.nnls_matrices(n_b, cfg)
         self.plan = api.NnlsPlan(self.basis, self.reg, device.index)
-        _, self.y = synth.make_torch("tri_reduced", self.n_vox, n_b, device, sigma=0.01, seed=synth.SEED + seed,
-                                     scale=1000.0)
+        _, self.y = synth.make_torch_rows("tri_reduced", rows[0], rows[1], n_b, device, sigma=0.01, scale=1000.0)
         nb = cfg["n_bins"]
         self.coeff = torch.empty((self.n_vox, nb), dtype=torch.float64, device=device)
         self.rnorm = torch.empty(self.n_vox, dtype=torch.float64, device=device)
@@ -130,6 +198,7 @@ class NnlsLeg:
         self.dtype = "f64"
         self.kernel = "nnls_kernel"
         self.model = "nnls"
+        self.device = device
 
     def step(self):
         stream = self.torch.cuda.current_stream().cuda_stream
@@ -139,6 +208,30 @@ class NnlsLeg:
     def check(self):
         return {"converged_frac": (self.status == 1).double().mean().item(),
                 "mean_iters": self.iters.double().mean().item()}
+
+    def host_mode(self, reps=1):
+        """PNX_MEM_HOST solve: numpy signal in, numpy (n_vox, 250) float64 spectra out.  The whole volume when the host
+        has the memory for its 8.4 GB result (twice: warm-up + timed), else its first 2^20 voxels."""
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 0
+        n = self.n_vox if avail > 6 * self.n_vox * self.cfg["n_bins"] * 8 else min(self.n_vox, 1 << 20)
+        y = self.y[:n].cpu().numpy()
+        self.plan.solve(y[: min(n, 1 << 16)], self.cfg["max_iter"])  # warm-up (slots, staging threads)
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            r = self.plan.solve(y, self.cfg["max_iter"])
+            ts.append(time.perf_counter() - t)
+        dt = float(np.mean(ts))
+        d2h = sum(a.nbytes for a in r.values())
+        same = bool((self.torch.from_numpy(r["coefficients"][:65536]).to(self.coeff.device) == self.coeff[:65536]).all().item())
+        return {"workload": f"{n} voxels of the same volume, host (numpy) arrays in and out through PNX_MEM_HOST",
+                "value": n / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes),
+                "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps,
+                "equals_device_resident_result": same}
 
     def cpu_baseline(self):
         from oracle import pnx_oracle as O
@@ -181,35 +274,45 @@ def timed(leg, steps, warmup, world, dist, torch):
     return dt, kernel_ms
 
 
-def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.sh -> profiles/r01_j_traffic.json;
-    FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is).  bench.py cannot run rocprofv3 around itself,
-    so the figure is the one measured on this kernel and this full-size workload when the profile was taken."""
-    try:
-        with open(os.path.join(HERE, "profiles", "r01_j_traffic.json")) as f:
-            t = json.load(f)
+# ---------------------------------------------------------------------------------------------------------------
+# PMC counters: bench.py cannot run rocprofv3 around itself, so HBM traffic and the instruction mix are replayed from
+# the committed passes (profiles/pmc_*.sh -> profiles/rNN_x_{traffic,flops}.json) -- but only from a profile stamped
+# with the source id of the kernel sources this run was built from (pyneapple_amd/_build.py:source_id); a kernel edit
+# without a new profile reports null, never stale counters.
+def _profile(kind: str, group: str):
+    import glob
+
+    from pyneapple_amd import _build
+
+    want = _build.source_id(group)
+    for f in sorted(glob.glob(os.path.join(HERE, "profiles", f"r*_{kind}.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+        except Exception:
+            continue
+        if t.get("_source_ids", {}).get(group) == want:
+            return t, os.path.relpath(f, HERE), want
+    return None, None, want
+
+
+def pmc_traffic(kernel_prefix: str, group: str):
+    """HBM bytes per launch (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes)."""
+    t, src, _ = _profile("traffic", group)
+    if t:
         for name, v in t.items():
             if kernel_prefix in name:
                 return v["hbm_bytes_per_launch"]
-    except Exception:
-        pass
     return None
 
 
-FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (MI355X_MICROARCH.md: half the 157.3 TF fp32 rate)
-
-
-def pmc_flops(kernel_prefix: str):
-    """fp64 flop per voxel ISSUED by the kernel (64 lanes per fp64 VALU instruction, FMA = 2), from the committed
-    PMC pass (profiles/r01_j_pmc_*.txt -> profiles/r01_j_flops.json)."""
-    try:
-        with open(os.path.join(HERE, "profiles", "r01_j_flops.json")) as f:
-            t = json.load(f)
+def pmc_flops(kernel_prefix: str, group: str):
+    """fp64 flop per voxel ISSUED by the kernel (64 lanes per fp64 VALU instruction, FMA = 2)."""
+    t, src, sid = _profile("flops", group)
+    if t:
         for name, v in t.items():
             if kernel_prefix in name:
-                return v
-    except Exception:
-        pass
+                return dict(v, source=src, source_id=sid)
     return None
 
 
@@ -222,14 +325,15 @@ def mfma_roofline(device, torch, reps=20):
     _, basis, reg = synth.nnls_matrices(n_b)
     plan = api.NnlsPlan(basis, reg, device.index)
     _, y = synth.make_torch("tri_reduced", n_vox, n_b, device, sigma=0.01, scale=1000.0)
+    aty = torch.empty((n_vox, 256), dtype=torch.float64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
-        plan.aty_device(n_vox, y, None, stream)
+        plan.aty_device(n_vox, y, aty, stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        plan.aty_device(n_vox, y, None, stream)
+        plan.aty_device(n_vox, y, aty, stream)
     e1.record()
     torch.cuda.synchronize()
     plan.close()
@@ -238,17 +342,12 @@ def mfma_roofline(device, torch, reps=20):
     ach = flops / (ms * 1e-3) / 1e12
     out_bytes = n_vox * 256 * 8 + n_vox * n_b * 8
     return {"bound": "mfma", "kernel": "nnls_aty_mfma_kernel (v_mfma_f64_16x16x4_f64)", "achieved": ach,
-            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": pmc_traffic("nnls_aty_mfma_kernel"),
+            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+            "traffic": pmc_traffic("nnls_aty_mfma_kernel", "nnls"),
             "algorithmic_flop_per_launch": flops, "kernel_ms_avg": ms, "dtype": "f64",
             "hbm_GBps": out_bytes / (ms * 1e-3) / 1e9,
             "note": "fp64 because an fp32 Gram product breaks NNLS parity (DESIGN.md 4.3); the (n_vox,256) fp64 product is "
                     "materialised, so the step is co-bound by its HBM write"}
-
-
-def nnls_traffic(n_vox):
-    """PMC HBM bytes of one NNLS step: the per-launch figure (one 2^20-voxel chunk) times the chunks per step."""
-    t = pmc_traffic("nnls_kernel")
-    return None if t is None else t * ((n_vox + (1 << 20) - 1) >> 20)
 
 
 def sweep_roofline(device, torch, n_vox_override=0, reps=20):
@@ -258,9 +357,7 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=20):
 
     model, n_b, shape = synth.WORKLOADS["triexp"]
     n_vox = n_vox_override or int(np.prod(shape))
-    b, y64 = synth.make_torch(model, n_vox, n_b, device, sigma=0.01)
-    y = y64.float()
-    del y64
+    b, y = synth.make_torch_rows(model, 0, n_vox, n_b, device, sigma=0.01, dtype=torch.float32)
     names, p0, _, _ = synth.shared_arrays(model)
     n = len(names)
     ntri = n * (n + 1) // 2
@@ -294,20 +391,41 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=20):
     ach = bytes_per * n_vox / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "sweep_kernel<tri_reduced,f32>", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None if n_vox_override else pmc_traffic("sweep_"),
+            "traffic": None if n_vox_override else pmc_traffic("sweep_", "sweep"),
             "algorithmic_bytes_per_launch": bytes_per * n_vox, "algorithmic_bytes_per_voxel": bytes_per,
             "kernel_ms_avg": ms, "per_launch_event_pair_ms_avg": ms_pair, "voxel_sweeps_per_s": n_vox / (ms * 1e-3), "dtype": "f32"}
 
 
-def main():
-    args = parse()
-    import torch
+WORKLOAD_TEXT = {
+    "triexp": "triexp bounded LM (SciPy-TRF parity), 256x256x64x32, fp64",
+    "biexp": "biexp bounded LM, 128x128x32x24, fp64",
+    "mono": "monoexp curvefit, 32x32x1x16, fp64",
+    "nnls": "NNLS reg_order=2 mu=0.02 n_bins=250, 256x256x64x32, fp64",
+}
 
-    from pyneapple_amd import _lib
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch(args, argv)  # nothing above has touched the GPU (torch is not even imported yet)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; run `python bench.py --gpus {args.gpus}` "
+                         f"(it spawns the ranks) or torch.distributed.run --nproc-per-node {args.gpus}\n")
+        return 2
+    n_total, rows = volume_rows(args.workload, args, rank, world)
+    if args.launch_check:
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local, "rows": rows, "n_vox_total": n_total}), flush=True)
+        return 0
+
+    import torch
+
+    from pyneapple_amd import _lib
+    from pyneapple_amd.sharding import shard_range
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -318,70 +436,86 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL; only used for the barrier and the max-reduce
+        world = dist.get_world_size()
     _lib.load()
 
     want_pcov = not args.no_pcov
     if args.workload == "nnls":
-        leg = NnlsLeg(device, args.voxels, seed=rank)
+        leg = NnlsLeg(device, n_total, rows)
     else:
-        leg = CurvefitLeg(args.workload, device, args.jac, want_pcov, args.voxels, seed=rank)
+        leg = CurvefitLeg(args.workload, device, args.jac, want_pcov, n_total, rows)
     dt, kernel_ms = timed(leg, args.steps, args.warmup, world, dist, torch)
-    total_vox = leg.n_vox * world * args.steps
-    value = total_vox / dt
+    value = n_total * args.steps / dt
     k_avg = float(np.mean(kernel_ms)) * 1e-3
     achieved = leg.bytes_per_voxel * leg.n_vox / k_avg / 1e9
+    full_c3 = args.workload == "triexp" and args.jac == "fd" and not args.voxels and world == 1
+    text = WORKLOAD_TEXT[args.workload]
+    if args.workload != "nnls":
+        text += ", FD Jacobian" if args.jac == "fd" else ", analytic Jacobian"
     out = {
         "metric": METRIC, "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": leg.dtype, "data": "synthetic",
-        "config": {"workload": {"triexp": "triexp bounded LM (SciPy-TRF parity), 256x256x64x32, fp64, FD Jacobian" if args.jac == "fd" else "triexp bounded LM, 256x256x64x32, fp64, analytic Jacobian",
-                                "biexp": "biexp bounded LM, 128x128x32x24, fp64",
-                                "mono": "monoexp curvefit, 32x32x1x16, fp64",
-                                "nnls": "NNLS reg_order=2 mu=0.02 n_bins=250, 256x256x64x32, fp64"}[args.workload],
-                   "voxels_per_gpu": leg.n_vox, "jac": args.jac if args.workload != "nnls" else None,
-                   "pcov": want_pcov if args.workload != "nnls" else None, "parallelism": f"voxel-shard x{world}",
+        "config": {"workload": text, "residency": "device-resident: the volume is in HBM when the timed region starts; "
+                                                  "PCIe-inclusive rate in host_mode",
+                   "voxels_total": n_total, "voxels_per_rank": [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)],
+                   "jac": args.jac if args.workload != "nnls" else None,
+                   "pcov": want_pcov if args.workload != "nnls" else None,
+                   "parallelism": f"one volume, contiguous voxel shards x{world}, no collective on the data path",
                    "full_size": not args.voxels},
         "roofline": {"bound": "hbm", "kernel": leg.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("curvefit_kernel<4, 5, true, false, false>") if (args.workload == "triexp" and args.jac == "fd" and not args.voxels) else None,
+                     "traffic": (pmc_traffic(CURVEFIT_C3_KERNEL, "curvefit") if full_c3 else
+                                 nnls_traffic(leg.n_vox) if (args.workload == "nnls" and not args.voxels and world == 1) else None),
                      "algorithmic_bytes_per_launch": leg.bytes_per_voxel * leg.n_vox,
                      "algorithmic_bytes_per_voxel": leg.bytes_per_voxel, "kernel_ms_avg": k_avg * 1e3,
-                     "note": "whole-fit kernel is fp64-VALU/transcendental bound, not HBM bound (DESIGN.md section 4)"},
+                     "note": "whole-fit kernels are fp64-VALU bound, not HBM bound (DESIGN.md section 4); rank 0's kernel"},
         "check": leg.check(),
     }
-    fl = pmc_flops("curvefit_kernel<4, 5, true, false, false>") if (args.workload == "triexp" and args.jac == "fd") else None
+    fl = pmc_flops(CURVEFIT_C3_KERNEL, "curvefit") if (args.workload == "triexp" and args.jac == "fd") else None
     if fl:  # the bound that actually applies: fp64 VALU issue (flop count from the committed PMC pass, time live)
         tf = fl["fp64_flop_per_voxel_issued"] * leg.n_vox / k_avg / 1e12
         out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                                        "fp64_flop_per_voxel_issued": fl["fp64_flop_per_voxel_issued"],
-                                       "lane_utilisation": fl["lane_utilisation"], "source": "profiles/r01_j_flops.json"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                                       "lane_utilisation": fl["lane_utilisation"], "source": fl["source"],
+                                       "source_id": fl["source_id"]}
+    solo = rank == 0 and world == 1
+    if solo and not args.no_host_mode:
+        out["host_mode"] = leg.host_mode()
+    if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = leg.cpu_baseline()
     if args.workload == "triexp" and not args.no_secondary:
         del leg
         torch.cuda.empty_cache()
-        leg2 = NnlsLeg(device, args.voxels, seed=rank)
-        dt2, k2 = timed(leg2, max(1, min(args.steps, 2)), 1 if args.warmup else 0, world, dist, torch)
+        n2, rows2 = volume_rows("nnls", args, rank, world)
+        leg2 = NnlsLeg(device, n2, rows2)
         steps2 = max(1, min(args.steps, 2))
+        dt2, k2 = timed(leg2, steps2, 1 if args.warmup else 0, world, dist, torch)
         k2avg = float(np.mean(k2)) * 1e-3
         ach2 = leg2.bytes_per_voxel * leg2.n_vox / k2avg / 1e9
-        sec = {"workload": "NNLS reg_order=2 mu=0.02 n_bins=250, 256x256x64x32, fp64", "value": leg2.n_vox * world * steps2 / dt2,
+        sec = {"workload": WORKLOAD_TEXT["nnls"], "value": n2 * steps2 / dt2,
                "unit": "voxels/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "check": leg2.check(),
                "roofline": {"bound": "hbm", "kernel": "nnls_kernel", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach2 / HBM_PEAK_GBS, "traffic": nnls_traffic(leg2.n_vox) if not args.voxels else None,
+                            "frac": ach2 / HBM_PEAK_GBS,
+                            "traffic": nnls_traffic(leg2.n_vox) if (not args.voxels and world == 1) else None,
                             "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel, "kernel_ms_avg": k2avg * 1e3,
-                            "note": "active-set loop is VALU-issue bound: 4 waves per SIMD keep the issue slots 74 % busy, 24 % of the instructions are fp64 arithmetic (DESIGN.md 4.3)"}}
-        fl2 = pmc_flops("nnls_kernel")
-        if fl2:  # the active-set kernel is VALU-issue bound (74 % of the SIMD issue slots, a quarter of them fp64)
+                            "note": "the active-set loop is VALU-issue bound (DESIGN.md 4.3)"}}
+        fl2 = pmc_flops("nnls_kernel", "nnls")
+        if fl2:
             tf2 = fl2["fp64_flop_per_voxel_issued"] * leg2.n_vox / k2avg / 1e12
             sec["roofline"]["valu_f64"] = {"achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf2 / FP64_PEAK_TFLOPS,
                                            "fp64_flop_per_voxel_issued": fl2["fp64_flop_per_voxel_issued"],
                                            "fp64_share_of_valu_instructions": fl2["fp64_share_of_valu_instructions"],
-                                           "lane_utilisation": fl2["lane_utilisation"], "source": "profiles/r01_j_flops.json"}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                                           "lane_utilisation": fl2["lane_utilisation"], "source": fl2["source"],
+                                           "source_id": fl2["source_id"]}
+        if solo and not args.no_host_mode:
+            sec["host_mode"] = leg2.host_mode()
+        if solo and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec
-    if args.workload == "triexp" and not args.no_secondary:
+        del leg2
+        torch.cuda.empty_cache()
+    if args.workload == "triexp" and not args.no_secondary and rank == 0:
         out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
         out["roofline_mfma"] = mfma_roofline(device, torch)
     if world > 1:
@@ -389,7 +523,18 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 0
+
+
+def nnls_traffic(n_vox):
+    """PMC HBM bytes of one NNLS step (per-launch figure x launches per step; see profiles/*_traffic.json:_nnls_launch_voxels)."""
+    t, _, _ = _profile("traffic", "nnls")
+    if not t:
+        return None
+    per = int(t.get("_nnls_launch_voxels", 1 << 20))
+    v = pmc_traffic("nnls_kernel", "nnls")
+    return None if v is None else v * ((n_vox + per - 1) // per)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,6 +22,30 @@ CURVEFIT_FLAGS = os.environ.get("PNX_CURVEFIT_FLAGS", "").split()
 NNLS_FLAGS = os.environ.get("PNX_NNLS_FLAGS", "").split()  # e.g. -DPNX_NNLS_GBATCH=8 -DPNX_NNLS_WAVES_PER_SIMD=3 -DPNX_NNLS_LDS_ROWS=56
 
 
+# kernel source groups: profiles/*_traffic.json / *_flops.json are stamped with source_id(group) of the build they were
+# measured on, and bench.py only replays counters whose stamp matches the sources it is running
+SOURCE_GROUPS = {
+    "curvefit": ["pnx_curvefit_kernel.hpp", "pnx_curvefit_inst.hip"],
+    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp"],
+    "sweep": ["pnx_sweep.hip"],
+}
+
+
+def source_id(group: str) -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in SOURCE_GROUPS[group]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(CXXFLAGS + (CURVEFIT_FLAGS if group == "curvefit" else NNLS_FLAGS if group == "nnls" else [])).encode())
+    return h.hexdigest()[:16]
+
+
+def source_ids() -> dict:
+    return {g: source_id(g) for g in SOURCE_GROUPS}
+
+
 def _units():
     units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_sweep.o", "pnx_sweep.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]

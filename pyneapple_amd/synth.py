@@ -63,24 +63,40 @@ def make_numpy(model: str, n_vox: int, n_b: int, sigma: float = 0.01, seed: int 
     return b, np.ascontiguousarray(y), P
 
 
-def make_torch(model: str, n_vox: int, n_b: int, device, sigma: float = 0.01, seed: int = SEED, scale: float = 1.0,
-               chunk: int = 1 << 20):
-    """Same distribution generated on `device` (float64), chunk-wise to bound temporaries."""
+ROW_CHUNK = 1 << 18  # rows per independently seeded block of a synthetic volume
+
+
+def make_torch_rows(model: str, start: int, stop: int, n_b: int, device, sigma: float = 0.01, seed: int = SEED,
+                    scale: float = 1.0, dtype=None):
+    """Rows [start, stop) of ONE seed-fixed synthetic volume, generated on `device` (float64).
+
+    The volume is defined block-wise: block c (rows c*ROW_CHUNK ...) is drawn from a generator seeded with
+    (seed, c), so any rank can produce any row range without the others, and the concatenation of the ranks'
+    shards is bit-identical to the volume a single process generates (bench.py --gpus N: strong scaling)."""
     import torch
 
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    dtype = dtype or torch.float64
     b = torch.linspace(0.0, 1200.0, n_b, dtype=torch.float64, device=device)
-    y = torch.empty((n_vox, n_b), dtype=torch.float64, device=device)
-    for s in range(0, n_vox, chunk):
-        n = min(chunk, n_vox - s)
+    y = torch.empty((max(0, stop - start), n_b), dtype=dtype, device=device)
+    g = torch.Generator(device=device)
+    for c in range(start // ROW_CHUNK, (max(stop, start + 1) - 1) // ROW_CHUNK + 1):
+        if stop <= start:
+            break
+        g.manual_seed(seed * 1000003 + c)
+        n = ROW_CHUNK
         P = {k: lo + (hi - lo) * torch.rand(n, generator=g, dtype=torch.float64, device=device)
              for k, (lo, hi) in TRUTH[model].items()}
         sig = _signal(torch, model, b, P) * scale
         if sigma:
             sig = sig * (1.0 + sigma * torch.randn(sig.shape, generator=g, dtype=torch.float64, device=device))
-        y[s:s + n] = sig
+        a, e = max(start, c * ROW_CHUNK), min(stop, (c + 1) * ROW_CHUNK)
+        y[a - start:e - start] = sig[a - c * ROW_CHUNK:e - c * ROW_CHUNK].to(dtype)
     return bvalues(n_b), y
+
+
+def make_torch(model: str, n_vox: int, n_b: int, device, sigma: float = 0.01, seed: int = SEED, scale: float = 1.0):
+    """The whole volume (rows [0, n_vox)) on `device`."""
+    return make_torch_rows(model, 0, n_vox, n_b, device, sigma, seed, scale)
 
 
 def shared_arrays(model: str):

@@ -1,0 +1,66 @@
+"""bench.py's multi-GPU plumbing on CPU: the launcher spawns N fresh ranks, the ranks shard ONE seed-fixed volume,
+and fitting the shards equals fitting the whole volume bit for bit (the per-rank fit here is the oracle -- there is
+no GPU in CI; on the MI355X node the same row ranges go through the C ABI)."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True,
+                          timeout=120)
+
+
+def test_launcher_spawns_n_ranks_that_partition_one_volume():
+    r = _run(["--gpus", "3", "--launch-check"])
+    assert r.returncode == 0, r.stderr
+    ranks = sorted((json.loads(l) for l in r.stdout.splitlines() if l.strip()), key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == [0, 1, 2] and all(d["world"] == 3 for d in ranks)
+    assert [d["local_rank"] for d in ranks] == [0, 1, 2]
+    n = ranks[0]["n_vox_total"]
+    assert n == 256 * 256 * 64
+    assert ranks[0]["rows"][0] == 0 and ranks[-1]["rows"][1] == n
+    assert all(a["rows"][1] == b["rows"][0] for a, b in zip(ranks[:-1], ranks[1:]))
+
+
+def test_gpus_flag_must_match_world_size():
+    r = _run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_single_process_default_is_one_rank():
+    r = _run(["--launch-check"])
+    assert r.returncode == 0
+    d = json.loads(r.stdout)
+    assert d["world"] == 1 and d["rows"] == [0, 256 * 256 * 64]
+
+
+def test_shards_of_the_volume_are_the_volume_and_fit_identically(oracle):
+    import torch
+
+    from pyneapple_amd import synth
+    from pyneapple_amd.sharding import shard_range
+
+    n = synth.ROW_CHUNK + 1234  # crosses a generator block boundary
+    _, whole = synth.make_torch_rows("tri_reduced", 0, n, 32, "cpu")
+    parts = [synth.make_torch_rows("tri_reduced", *shard_range(n, r, 3), 32, "cpu")[1] for r in range(3)]
+    assert torch.equal(torch.cat(parts), whole)
+    # fit a window around the first shard boundary whole and sharded: identical rows
+    b = synth.bvalues(32)
+    _, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    cut = shard_range(n, 0, 3)[1]
+    win = whole[cut - 40:cut + 40].numpy()
+    ref = oracle.curvefit("tri_reduced", b, win, p0, lo, hi)
+    left = oracle.curvefit("tri_reduced", b, parts[0][-40:].numpy(), p0, lo, hi)
+    right = oracle.curvefit("tri_reduced", b, parts[1][:40].numpy(), p0, lo, hi)
+    np.testing.assert_array_equal(np.concatenate([left["popt"], right["popt"]], axis=1), ref["popt"])
