@@ -18,6 +18,8 @@ import time
 
 import numpy as np
 
+from .fitters import HipFitterBase
+
 _INTERPOLATION_METHODS = ("linear", "cubic")
 
 
@@ -70,23 +72,31 @@ def resize2d(array: np.ndarray, target_shape, method: str = "cubic") -> np.ndarr
     return np.ascontiguousarray(np.swapaxes(out, 0, 1))   # (tx, ty, ...)
 
 
-class HipIDEALFitter:
+class HipIDEALFitter(HipFitterBase):
     """IDEAL pyramid around a `HipCurveFitSolver` (any solver with the CurveFitSolver interface works).
 
     Args follow IDEALFitter.__init__ (ideal.py:46-92): solver, dim_steps (n_steps, ideal_dims), step_tol
     {param: fraction}, ideal_dims, segmentation_threshold, interpolation_method ("linear" | "cubic").
+    `dim_steps` / `step_tol` may be left out at construction -- `FittingConfig.build_fitter` builds a plugin fitter
+    as `cls(solver=solver)` and forwards `[Fitting.ideal]` only to the built-in "ideal" type (io/toml.py:217-236) --
+    and assigned as attributes before `fit`, which raises a ValueError naming them otherwise.
     After `fit`: `step_params` (one (X, Y, Z, n_params) map per level), `fitted_params_`, `pixel_indices`,
-    `fit_time`.
+    `image_shape`, `results_` (FitResult of the last level), `fit_time`, `level_stats_` (device path: per level the mean
+    cost at the level's start values -- one pass of the residual sweep kernel, pnx_sweep_f64 -- and at the estimates).
     """
 
-    def __init__(self, solver, dim_steps, step_tol: dict, ideal_dims: int = 2, segmentation_threshold: float = 0.2,
-                 interpolation_method: str = "cubic", device_resident: bool | None = None, **fitter_kwargs):
+    def __init__(self, solver, dim_steps=None, step_tol: dict | None = None, ideal_dims: int = 2,
+                 segmentation_threshold: float = 0.2, interpolation_method: str = "cubic",
+                 device_resident: bool | None = None, keep_level_inputs: bool = False, **fitter_kwargs):
         if interpolation_method not in _INTERPOLATION_METHODS:
             raise ValueError(
                 f"Invalid interpolation method: {interpolation_method}. Must be one of {_INTERPOLATION_METHODS}.")
-        self.solver = solver
-        self.dim_steps = np.asarray(dim_steps)
+        super().__init__(solver=solver, **fitter_kwargs)
+        self.dim_steps = None if dim_steps is None else np.asarray(dim_steps)
         self.step_tol = step_tol
+        self.keep_level_inputs = keep_level_inputs  # device path: keep the last level's per-voxel p0 / bounds in HBM
+        self.last_level_inputs_ = None
+        self.level_stats_: list[dict] = []
         self.ideal_dims = ideal_dims
         self.segmentation_threshold = segmentation_threshold
         self.interpolation_method = interpolation_method
@@ -95,12 +105,16 @@ class HipIDEALFitter:
         # HipCurveFitSolver without fixed parameters and torch (device memory) is importable
         self.device_resident = device_resident
         self.step_params: list[np.ndarray] = []
-        self.fitted_params_: dict = {}
-        self.pixel_indices = None
         self.fit_time = None
 
     # ideal.py:261-297 --------------------------------------------------------------------------
     def _validate(self, xdata, image):
+        if self.dim_steps is None or self.step_tol is None:
+            raise ValueError(
+                "HipIDEALFitter needs dim_steps (n_steps, ideal_dims) and step_tol {param: fraction}: pass them to the "
+                "constructor or assign fitter.dim_steps / fitter.step_tol before fit() (a fitter built from a TOML config "
+                "receives only the solver: io/toml.py forwards [Fitting.ideal] to the built-in 'ideal' type alone).")
+        self.dim_steps = np.asarray(self.dim_steps)
         if np.ndim(xdata) != 1:
             raise ValueError(f"xdata must be a 1D array, but got shape {np.shape(xdata)}.")
         if image.shape[-1] != len(xdata):
@@ -133,6 +147,10 @@ class HipIDEALFitter:
     def fit(self, xdata, image, segmentation=None, **fit_kwargs):
         xdata = np.asarray(xdata, float)
         image = self._validate(xdata, np.asarray(image))
+        self.n_measurements = len(xdata)
+        self.image_shape = image.shape
+        self.level_stats_ = []
+        self.last_level_inputs_ = None
         t0 = time.perf_counter()
         if self.ideal_dims == 2 and image.ndim == 4:
             dim_steps = np.hstack([self.dim_steps, np.full((self.dim_steps.shape[0], 1), image.shape[2])])
@@ -186,6 +204,7 @@ class HipIDEALFitter:
         self.pixel_indices = np.stack(idx, axis=1)  # (n_px, 3), C order of np.where
         self.fitted_params_ = dict(self.solver.params_)
         self.fit_time = time.perf_counter() - t0
+        self.results_ = self._assemble(xdata, pixels, self.fit_time)  # ideal.py:256-259: FitResult of the final level
         return self
 
     # ------------------------------------------------------------------ device-resident pyramid
@@ -266,8 +285,28 @@ class HipIDEALFitter:
             opts = api.make_opts(s._kernel_model, N, [], per_voxel, False, int(s.max_iter), float(s.tol), 1e-8, 1e-8,
                                  s.jacobian_mode, kw["t1_mode"], kw["tr"], kw["tm"])
             t_b = time.perf_counter()
-            api.curvefit_device(opts, n_px, xdata, pixels.contiguous(), p0_a, lo_a, hi_a, None, popt, pcov, status, nfev, cost,
+            pixels = pixels.contiguous()
+            cost0 = None
+            if per_voxel and kw["t1_mode"] == 0:
+                # cost at the level's start values: one pass of the HBM-streaming residual sweep (pnx_sweep_f64) over
+                # the same signal rows and the parameter-major p0 array the fit is about to start from
+                cost0 = torch.empty(n_px, dtype=torch.float64, device=dev)
+                g0 = torch.empty((n, n_px), dtype=torch.float64, device=dev)
+                h0 = torch.empty((n * (n + 1) // 2, n_px), dtype=torch.float64, device=dev)
+                api.sweep_device(s._kernel_model, n_px, xdata, pixels, p0_d, cost0, g0, h0, dev_i, stream)
+                del g0, h0
+            api.curvefit_device(opts, n_px, xdata, pixels, p0_a, lo_a, hi_a, None, popt, pcov, status, nfev, cost,
                                 dev_i, stream)
+            stats = {"shape": shape, "n_pixels": n_px, "converged_frac": float((status > 0).double().mean()),
+                     "cost_mean": float(cost.mean())}
+            if cost0 is not None:
+                ok = status > 0
+                stats["cost_p0_mean"] = float(cost0.mean())
+                # TRF never accepts a step that raises the cost: the estimate is at least as good as the start value
+                stats["not_worse_than_p0_frac"] = float((cost[ok] <= cost0[ok] * (1 + 1e-12)).double().mean()) if bool(ok.any()) else 1.0
+            self.level_stats_.append(stats)
+            if last and self.keep_level_inputs and per_voxel:
+                self.last_level_inputs_ = {"p0": p0_d, "lo": lo_d, "hi": hi_d, "idx": idx, "cost_p0": cost0}
             if all_px:
                 pmap = popt.t().contiguous().reshape(tx, ty, Z, n)
             else:
@@ -281,9 +320,12 @@ class HipIDEALFitter:
             self.stage_times_.append((round(t_b - t_a, 3), round(t_c - t_b, 3), round(time.perf_counter() - t_c, 3)))
         res = {"popt": popt.cpu().numpy(), "pcov": pcov.cpu().numpy(), "status": status.cpu().numpy(),
                "nfev": nfev.cpu().numpy(), "cost": cost.cpu().numpy()}
+        ss_tot = (pixels.var(dim=1, unbiased=False) * N).cpu().numpy()  # SS_tot of the fitted rows, reduced in HBM
         s._reset_state()
         s._pack(res, n_px, list(names))  # the solver ends in the state solver.fit() of the last level leaves it in
         self.pixel_indices = (torch.ones(shape, dtype=torch.bool) if all_px else mask.cpu()).nonzero().numpy()
         self.fitted_params_ = dict(s.params_)
         self.fit_time = time.perf_counter() - t0
+        host_pixels = image.reshape(-1, N) if all_px else image[mask.cpu().numpy()]
+        self.results_ = self._assemble(xdata, host_pixels, self.fit_time, ss_tot=ss_tot)
         return self

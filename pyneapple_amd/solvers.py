@@ -26,6 +26,9 @@ _CURVEFIT_MESSAGES = {
     -3: "Initial guess is outside of provided bounds",
     -4: "Residuals are not finite in the initial point.",
 }
+# scipy.optimize.curve_fit / least_squares arguments whose SciPy default is what the kernel computes
+_CURVE_FIT_DEFAULTS = {"sigma": None, "absolute_sigma": False, "check_finite": True, "nan_policy": None, "loss": "linear",
+                       "x_scale": 1.0, "f_scale": 1.0, "tr_solver": None, "full_output": False}
 _NNLS_MESSAGES = {0: "Maximum number of iterations reached.", -2: "array must not contain infs or NaNs"}
 
 
@@ -91,7 +94,11 @@ def _split(n: int, parts: int):
 class HipCurveFitSolver(CurveFitBase):
     """Batched bounded NLLS on MI355X with SciPy `curve_fit(method="trf")` semantics.
 
-    Args mirror CurveFitSolver (curvefit.py:36-89).  Extra keyword arguments:
+    Args mirror CurveFitSolver (curvefit.py:36-89).  `use_jacobian` is stored and, as in the reference (curvefit.py:289-293
+    passes `jac_fn`, which is None without fixed parameters), does not select the Jacobian: finite differences without
+    fixed parameters, the analytic model Jacobian with them.  `multi_threading` / `n_pools` describe the reference's
+    joblib pool and have no meaning here.  Extra keyword arguments:
+        xtol, gtol: least_squares tolerances (SciPy default 1e-8); any other curve_fit argument is refused.
         jacobian: "fd" (default; SciPy 2-point finite differences, what the reference uses when no parameter
             is fixed) or "analytic" (model Jacobian; always used when parameters are fixed, like the reference).
         device: first HIP device index (default 0).  n_gpus: number of devices to shard voxels over (default 1).
@@ -110,6 +117,21 @@ class HipCurveFitSolver(CurveFitBase):
         self.io_dtype = _io_dtype(solver_kwargs.pop("io_dtype", "float64"))
         if self.jacobian_mode not in ("fd", "analytic"):
             raise ValueError("jacobian must be 'fd' or 'analytic'")
+        # The reference forwards every remaining key into scipy.optimize.curve_fit (curvefit.py:295-306).  The kernel
+        # implements least_squares' xtol / gtol; anything else would change SciPy's result and there is no CPU path to
+        # honour it, so it is refused instead of being dropped silently (keys at their SciPy default are accepted).
+        self.xtol = float(solver_kwargs.pop("xtol", 1e-8))
+        self.gtol = float(solver_kwargs.pop("gtol", 1e-8))
+        for key, default in _CURVE_FIT_DEFAULTS.items():
+            if key in solver_kwargs:
+                v = solver_kwargs.pop(key)
+                if not (v is default or v == default):
+                    raise ValueError(f"HipCurveFitSolver does not implement curve_fit({key}={v!r}); only the SciPy "
+                                     f"default ({default!r}) is supported")
+        unknown = set(solver_kwargs) - {"n_pools"}
+        if unknown:
+            raise ValueError(f"HipCurveFitSolver got solver arguments it cannot honour: {sorted(unknown)} "
+                             "(supported: xtol, gtol, jacobian, device, n_gpus, io_dtype, n_pools)")
         if method != "trf":
             raise ValueError(f"HipCurveFitSolver implements method='trf' only (got {method!r}); "
                              "use the reference CurveFitSolver for 'dogbox' / 'lm'.")
@@ -203,6 +225,7 @@ class HipCurveFitSolver(CurveFitBase):
     # ------------------------------------------------------------------ fit (curvefit.py:91-159)
     def fit(self, xdata: np.ndarray, ydata: np.ndarray, p0=None, bounds=None,
             pixel_fixed_params: dict[str, np.ndarray] | None = None, **fit_kwargs) -> "HipCurveFitSolver":
+        # **fit_kwargs: accepted and unused, exactly like the reference (curvefit.py:91-159 never reads them)
         self._reset_state()
         xdata = np.asarray(xdata)
         ydata = np.asarray(ydata)
@@ -256,7 +279,8 @@ class HipCurveFitSolver(CurveFitBase):
 
     def _run(self, xdata, ydata, p0, lo, hi, per_voxel, fixed_idx, fixed_vals, jac):
         n_vox = ydata.shape[0]
-        kw = dict(max_nfev=int(self.max_iter), ftol=float(self.tol), jac=jac, fixed_idx=fixed_idx, **self._kernel_t1)
+        kw = dict(max_nfev=int(self.max_iter), ftol=float(self.tol), xtol=self.xtol, gtol=self.gtol, jac=jac,
+                  fixed_idx=fixed_idx, **self._kernel_t1)
         n_dev = max(1, min(self.n_gpus, n_vox))
         if n_dev == 1:
             return api.curvefit(self._kernel_model, xdata, ydata, p0, lo, hi, fixed_vals=fixed_vals,

@@ -41,8 +41,11 @@ class TestOnGpu:
         maps = f.parameter_maps()
         assert maps["S0"].shape == (6, 5, 2) and maps["S0"].dtype == np.float32
         assert (maps["S0"][seg == 0] == 0).all() and np.allclose(maps["S0"][seg != 0], S0[seg != 0], rtol=1e-3)
-        pred = f.predict(B8)
-        np.testing.assert_allclose(pred, img[seg != 0], rtol=1e-5)
+        pred = f.predict(B8)  # (X, Y, Z, N) volume, zeros outside the mask (fitters/base.py:90-131)
+        assert pred.shape == img.shape and (pred[seg == 0] == 0).all()
+        np.testing.assert_allclose(pred[seg != 0], img[seg != 0], rtol=1e-5)
+        np.testing.assert_allclose(f.predict_pixels(B8), img[seg != 0], rtol=1e-5)
+        assert f.get_fitted_params() is f.fitted_params_
         assert r.solver_name == "HipCurveFitSolver" and r.model_name == "MonoExpModel"
 
     def test_fixed_param_maps_and_failures(self, gpu):

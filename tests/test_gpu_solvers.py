@@ -146,3 +146,23 @@ def test_t1_model_with_fixed_t1_map_through_the_plugin(gpu):
     assert set(s.params_) == {"S0", "D"}
     got = np.stack([s.params_["S0"], s.params_["D"]], axis=1)
     assert (np.abs(got - d["popt"]) <= 1e-8 * np.abs(d["popt"])).all()
+
+
+def test_xtol_gtol_solver_kwargs_reach_the_kernel(gpu, oracle):
+    """`[Fitting.solver] xtol = ...` arrives as a constructor kwarg and the reference forwards it to curve_fit
+    (curvefit.py:295-306): a loose xtol / gtol must change the termination exactly as it does in the oracle."""
+    from pyneapple_amd import synth
+
+    b, y, _ = synth.make_numpy("bi_reduced", 2000, 24, sigma=0.01, seed=3)
+    names, p0, lo, hi = synth.shared_arrays("bi_reduced")
+    default = bi_solver().fit(b, y)
+    for kw in (dict(xtol=1e-3), dict(gtol=1e-4), dict(xtol=1e-4, gtol=1e-5)):
+        s = bi_solver(**kw).fit(b, y)
+        ref = oracle.curvefit("bi_reduced", b, y, p0, lo, hi, max_nfev=250, ftol=1e-8, jac="fd", **kw)
+        st = np.asarray(s.diagnostics_["status"])
+        assert (st == ref["status"]).mean() > 0.995
+        assert (np.asarray(s.diagnostics_["nfev"]) == ref["nfev"]).mean() > 0.99
+        assert (st != np.asarray(default.diagnostics_["status"])).mean() > 0.2  # the tolerance really took effect
+        got = np.stack([s.params_[n] for n in names])
+        rel = np.abs(got - ref["popt"]) / np.maximum(np.abs(ref["popt"]), 1e-300)
+        assert (rel.max(axis=0) <= 1e-4).mean() >= 0.99

@@ -114,6 +114,21 @@ class TestCurveFitSolverHostSide:
         p0, lo, hi, pv = s._prepare_p0_bounds(arr, None, 5)
         assert pv and p0.shape == (2, 5) and lo.shape == (2, 5) and (lo[0] == 1.0).all()
 
+    def test_solver_kwargs_are_honoured_or_refused(self):
+        """Extra [Fitting.solver] keys reach the constructor as kwargs (io/toml.py:328-338); the reference forwards them to
+        curve_fit (curvefit.py:295-306).  xtol / gtol are implemented, SciPy defaults are accepted, the rest is refused."""
+        kw = dict(model=MonoExpModel(), max_iter=250, tol=1e-8, p0={"S0": 1000.0, "D": 1e-3},
+                  bounds={"S0": (1.0, 5000.0), "D": (1e-5, 0.1)})
+        s = HipCurveFitSolver(**kw, xtol=1e-10, gtol=1e-6, n_pools=4, multi_threading=True, device=0, n_gpus=1,
+                              jacobian="fd", io_dtype="float64", absolute_sigma=False, loss="linear", x_scale=1.0)
+        assert s.xtol == 1e-10 and s.gtol == 1e-6
+        for bad in (dict(sigma=np.ones(8)), dict(loss="soft_l1"), dict(x_scale="jac"), dict(absolute_sigma=True),
+                    dict(typo_key=1)):
+            with pytest.raises(ValueError):
+                HipCurveFitSolver(**kw, **bad)
+        with pytest.raises(ValueError):
+            HipCurveFitSolver(**kw, method="dogbox")
+
     def test_fit_without_gpu_fails_loudly(self):
         if _lib.device_count() > 0:
             pytest.skip("a HIP device is visible here")

@@ -95,6 +95,22 @@ def test_levels_shapes_bounds_and_fallback():
     assert len(f.pixel_indices) == 2 and set(f.fitted_params_) == {"f1", "D1", "D2"}
 
 
+def test_ideal_fitter_built_the_way_a_toml_config_builds_plugins():
+    """io/toml.py:236 builds a plugin fitter as cls(solver=solver): construction must work, fit must name what is missing,
+    and assigning the attributes afterwards must be enough."""
+    s = _FakeSolver()
+    f = HipIDEALFitter(solver=s)
+    b = np.linspace(0, 1000, 8)
+    img = np.ones((8, 8, 1, 8))
+    with pytest.raises(ValueError, match="dim_steps"):
+        f.fit(b, img)
+    f.dim_steps = [[4, 4], [8, 8]]
+    f.step_tol = {"f1": .2, "D1": .2, "D2": .2}
+    f.fit(b, img)
+    assert f.image_shape == (8, 8, 1, 8) and f.n_measurements == 8 and f.results_.n_pixels == 64
+    assert f.predict(b).shape == (8, 8, 1, 8)
+
+
 def test_validation_errors():
     s = _FakeSolver()
     b = np.linspace(0, 1000, 8)
@@ -184,3 +200,68 @@ def test_device_resident_pyramid_equals_host_pyramid(gpu):
             np.testing.assert_allclose(fd.fitted_params_[k], fh.fitted_params_[k], rtol=1e-6)
         np.testing.assert_array_equal(sd.diagnostics_["status"], sh.diagnostics_["status"])
         assert sd.diagnostics_["pcov"].shape == sh.diagnostics_["pcov"].shape and len(sd.pixel_results_) == len(sh.pixel_results_)
+
+
+@pytest.mark.gpu
+def test_config5_triexp_three_levels_full_size(gpu, oracle):
+    """BASELINE configs[4]: IDEAL multi-resolution triexp, 64^2 -> 128^2 -> 256^2, 64 slices, 32 b-values, through the
+    HBM-resident pyramid (fitters/ideal.py:167-254 of the reference).  Size-independent properties on all 4.19 M
+    voxels, and the oracle on 4 096 random voxels of the last level with the SAME per-voxel p0 / bounds arrays the
+    device used (read back from HBM)."""
+    import torch
+
+    from pyneapple_amd import synth
+    from pyneapple_amd.models import TriExpModel
+    from pyneapple_amd.solvers import HipCurveFitSolver
+
+    shape = (256, 256, 64)
+    n = int(np.prod(shape))
+    b, y = synth.make_torch("tri_reduced", n, 32, torch.device("cuda", 0), sigma=0.01)
+    img = y.cpu().numpy().reshape(*shape, 32)
+    del y
+    names, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    solver = HipCurveFitSolver(model=TriExpModel(), max_iter=250, tol=1e-8, p0=dict(zip(names, p0)),
+                               bounds={k: (a, c) for k, a, c in zip(names, lo, hi)})
+    steps = np.array([[64, 64], [128, 128], [256, 256]])
+    tol = {k: 0.5 for k in names}
+    f = HipIDEALFitter(solver, steps, tol, interpolation_method="cubic", device_resident=True, keep_level_inputs=True)
+    f.fit(b, img)
+    # level shapes
+    assert [p.shape for p in f.step_params] == [(64, 64, 64, 5), (128, 128, 64, 5), (256, 256, 64, 5)]
+    assert [s["n_pixels"] for s in f.level_stats_] == [64 * 64 * 64, 128 * 128 * 64, n]
+    assert f.results_.n_pixels == n and f.image_shape == (*shape, 32) and f.pixel_indices.shape == (n, 3)
+    # the levels below the first start from the previous level's map: never worse than their start values
+    for s in f.level_stats_[1:]:
+        assert s["not_worse_than_p0_frac"] == 1.0 and s["cost_mean"] <= s["cost_p0_mean"]
+        assert s["converged_frac"] > 0.999
+    # every estimate of the last level inside its per-voxel bounds (read back from the device)
+    L = f.last_level_inputs_
+    popt = np.stack([solver.params_[k] for k in names])          # (5, n)
+    lo_d, hi_d, p0_d = (L[k].cpu().numpy() for k in ("lo", "hi", "p0"))
+    ok = np.asarray(solver.diagnostics_["status"]) > 0
+    assert (popt >= lo_d).all() and (popt <= hi_d).all()
+    assert (lo_d >= lo[:, None]).all() and (hi_d <= hi[:, None]).all()   # clipped to the global bounds (ideal.py:176-184)
+    np.testing.assert_array_equal(p0_d, np.clip(p0_d, lo[:, None], hi[:, None]))
+    # the sweep kernel's cost at p0 against the oracle's residuals at p0 (max_nfev=1: one evaluation, at the start values)
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(n, 4096, replace=False))
+    ysub = np.ascontiguousarray(img.reshape(-1, 32)[sub])
+    args = (np.ascontiguousarray(p0_d[:, sub]), np.ascontiguousarray(lo_d[:, sub]), np.ascontiguousarray(hi_d[:, sub]))
+    at_p0 = oracle.curvefit("tri_reduced", b, ysub, *args, max_nfev=1)
+    inside = ((args[0] > args[1]) & (args[0] < args[2])).all(axis=0) & (at_p0["status"] >= 0)
+    np.testing.assert_allclose(L["cost_p0"].cpu().numpy()[sub][inside], at_p0["cost"][inside], rtol=1e-9)
+    # the oracle leg: same rows, same per-voxel start values and bounds -> same estimates
+    ref = oracle.curvefit("tri_reduced", b, ysub, *args, max_nfev=250, ftol=1e-8, jac="fd", n_threads=8)
+    np.testing.assert_array_equal(ref["status"] > 0, ok[sub])
+    good = ref["status"] > 0
+    rel = np.abs(popt[:, sub] - ref["popt"]) / np.maximum(np.abs(ref["popt"]), 1e-300)
+    within = (rel.max(axis=0) <= 1e-4)[good]
+    # per-voxel boxes are tight (p0 * (1 -/+ 0.5)): the optimum usually sits on a face, where TRF's answer is sharp
+    assert within.mean() >= 0.995, f"only {within.mean():.4f} of the subset within rtol 1e-4 of the oracle"
+    np.testing.assert_allclose(np.asarray(solver.diagnostics_["cost"])[sub][good], ref["cost"][good], rtol=1e-5)
+    # R^2 assembled from the kernel's cost and the HBM-side SS_tot reduction
+    r2 = f.results_.r_squared
+    pred = f.predict_pixels(b)[sub]
+    ss_res = ((ysub - pred) ** 2).sum(axis=1)
+    ss_tot = ((ysub - ysub.mean(axis=1, keepdims=True)) ** 2).sum(axis=1)
+    np.testing.assert_allclose(r2[sub][good], (1 - ss_res / ss_tot)[good], rtol=1e-9, atol=1e-12)
