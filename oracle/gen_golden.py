@@ -263,6 +263,120 @@ def main_g8():
                  mono_p0, mono_bd, 16, 64, [0.0, 0.01], rng, fixed={"S0": (500, 1500), "T1": (800, 1600)})
 
 
+def main_g9():
+    """Fourth batch (round 2): the reference's own PixelWiseFitter result assembly (fitters/base.py:142-253), the
+    reference-default 250-bin reg_order=0 NNLS, three fixed parameters, and NNLS spectrum post-processing
+    (utility/spectrum.py:13-139)."""
+    from pyneapple import BiExpModel, CurveFitSolver, NNLSModel, NNLSSolver, PixelWiseFitter, TriExpModel
+    from pyneapple.utility.spectrum import apply_cutoffs, find_spectrum_peaks
+
+    rng = np.random.default_rng(SEED + 9)
+    # --- f-2: PixelWiseFitter(CurveFitSolver) with a mask and one NaN voxel
+    b = np.linspace(0.0, 1200.0, 24)
+    shape = (6, 5, 2)
+    f1 = rng.uniform(0.1, 0.4, shape)
+    D1 = rng.uniform(5e-3, 5e-2, shape)
+    D2 = rng.uniform(5e-4, 2e-3, shape)
+    img = f1[..., None] * np.exp(-b * D1[..., None]) + (1 - f1[..., None]) * np.exp(-b * D2[..., None])
+    img = img * (1.0 + 0.01 * rng.standard_normal(img.shape))
+    seg = np.zeros(shape, dtype=int)
+    seg[1:5, :, :] = 1
+    seg[2, 2, 0] = 0
+    img[3, 1, 1, 4] = np.nan          # inside the mask: curve_fit raises -> failure sentinel, R^2 NaN
+    img[1, 0, 0, :] = 0.75            # constant signal inside the mask: SS_tot = 0 -> R^2 NaN (base.py:182)
+    bi_p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001}
+    bi_bd = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}
+
+    def run(fixed_maps):
+        solver = CurveFitSolver(model=BiExpModel(), max_iter=250, tol=1e-8, p0=bi_p0, bounds=bi_bd)
+        fit = PixelWiseFitter(solver)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fit.fit(b, img, segmentation=seg, fixed_param_maps=fixed_maps)
+        r = fit.results_
+        return dict(bvalues=b, image=img, segmentation=seg, r_squared=r.r_squared, success=r.success,
+                    pixel_indices=np.array(r.pixel_indices), covariance=r.covariance, n_pixels=r.n_pixels,
+                    param_names=np.array(list(r.params)), params=np.stack([np.asarray(v) for v in r.params.values()]),
+                    messages_none=np.array([m is None for m in (r.messages or [None] * r.n_pixels)]),
+                    p0_vals=np.array(list(bi_p0.values())), lo_vals=np.array([v[0] for v in bi_bd.values()]),
+                    hi_vals=np.array([v[1] for v in bi_bd.values()]), **_versions())
+
+    out = run(None)
+    np.savez_compressed(os.path.join(OUT, "g9_pixelwise_bi.npz"), **out)
+    print(f"g9_pixelwise_bi: n_px={out['n_pixels']} success={out['success'].mean():.3f} r2 nan={np.isnan(out['r_squared']).sum()}")
+    out = run({"D1": D1})
+    np.savez_compressed(os.path.join(OUT, "g9_pixelwise_bi_fixedmap.npz"), fixed_D1=D1, **out)
+    print(f"g9_pixelwise_bi_fixedmap: n_px={out['n_pixels']} success={out['success'].mean():.3f} r2 nan={np.isnan(out['r_squared']).sum()}")
+
+    # --- f-2: PixelWiseFitter(NNLSSolver): residuals and the basis-path R^2 (base.py:162-169)
+    bn = np.linspace(0.0, 1200.0, 16)
+    tri = TriExpModel()
+    shape_n = (4, 3, 2)
+    n = int(np.prod(shape_n))
+    truth = np.column_stack([rng.uniform(0.1, 0.3, n), rng.uniform(0.03, 0.1, n), rng.uniform(0.2, 0.4, n),
+                             rng.uniform(3e-3, 8e-3, n), rng.uniform(5e-4, 1.5e-3, n)])
+    imgn = (np.array([tri.forward(bn, *t) for t in truth]) * 1000.0).reshape(*shape_n, 16)
+    imgn = imgn * (1.0 + 0.01 * rng.standard_normal(imgn.shape))
+    segn = np.ones(shape_n, dtype=int)
+    segn[0, 0, :] = 0
+    model = NNLSModel(d_range=(1e-4, 0.1), n_bins=50)
+    fit = PixelWiseFitter(NNLSSolver(model=model, reg_order=2, mu=0.02, max_iter=250))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit.fit(bn, imgn, segmentation=segn)
+    r = fit.results_
+    np.savez_compressed(os.path.join(OUT, "g9_pixelwise_nnls.npz"), bvalues=bn, image=imgn, segmentation=segn,
+                        d_range=np.array([1e-4, 0.1]), n_bins=50, reg_order=2, mu=0.02, max_iter=250,
+                        r_squared=r.r_squared, success=r.success, residuals=r.residuals,
+                        pixel_indices=np.array(r.pixel_indices), coefficients=r.params["coefficients"],
+                        covariance_is_none=np.array(r.covariance is None), **_versions())
+    print(f"g9_pixelwise_nnls: n_px={r.n_pixels} mean r2={np.nanmean(r.r_squared):.6f}")
+
+    # --- the reference's DEFAULT regulariser: reg_order=0 (nnls_solver.py:37), 250 bins -- rank deficient A
+    gen_nnls("g9_nnls_250_r0", (0.0008, 0.5), 250, 0, 0.02, 32, 48, rng)
+
+    # --- three fixed parameters (SegmentedFitter step 2 with all diffusivities from step 1; models/base.py:145-230)
+    tri_tr = {"f1": (0.1, 0.3), "D1": (0.03, 0.1), "f2": (0.2, 0.4), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3), "S0": (500, 1500)}
+    tri_p0 = {"f1": 0.2, "D1": 0.05, "f2": 0.3, "D2": 0.005, "D3": 0.001, "S0": 1000.0}
+    tri_bd = {"f1": (0.0, 1.0), "D1": (0.01, 0.5), "f2": (0.0, 1.0), "D2": (2e-3, 0.01), "D3": (1e-5, 2e-3), "S0": (1.0, 5000.0)}
+    gen_curvefit("g9_tri_s0_fixed_D1_D2_D3", TriExpModel(fit_s0=True), ["f1", "D1", "f2", "D2", "D3", "S0"], tri_tr, tri_p0,
+                 tri_bd, 32, 96, [0.0, 0.01], rng, fixed={"D1": (0.03, 0.1), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)})
+    full_tr = {"f1": (100, 300), "D1": (0.03, 0.1), "f2": (200, 400), "D2": (3e-3, 8e-3), "f3": (300, 700), "D3": (5e-4, 1.5e-3)}
+    full_p0 = {"f1": 200.0, "D1": 0.05, "f2": 300.0, "D2": 0.005, "f3": 500.0, "D3": 0.001}
+    full_bd = {"f1": (0.0, 2000.0), "D1": (0.01, 0.5), "f2": (0.0, 2000.0), "D2": (2e-3, 0.01), "f3": (0.0, 2000.0), "D3": (1e-5, 2e-3)}
+    gen_curvefit("g9_tri_full_fixed_D1_D2_D3", TriExpModel(fit_reduced=False), ["f1", "D1", "f2", "D2", "f3", "D3"], full_tr,
+                 full_p0, full_bd, 32, 96, [0.0, 0.01], rng, fixed={"D1": (0.03, 0.1), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)})
+    gen_curvefit("g9_tri_fixed_4_of_5", TriExpModel(), ["f1", "D1", "f2", "D2", "D3"], tri_tr, {k: tri_p0[k] for k in ("f1", "D1", "f2", "D2", "D3")},
+                 {k: tri_bd[k] for k in ("f1", "D1", "f2", "D2", "D3")}, 32, 64, [0.0, 0.01], rng,
+                 fixed={"D1": (0.03, 0.1), "f2": (0.2, 0.4), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)})
+
+    # --- NNLS spectrum post-processing on reference spectra (utility/spectrum.py:13-139)
+    MAXP = 8
+    cutoffs = [(0.0008, 0.003), (0.003, 0.02), (0.02, 0.5)]
+    for src, regularized in (("g4_nnls_250_r2", True), ("g4_nnls_250_r1", True), ("g9_nnls_250_r0", False)):
+        d = np.load(os.path.join(OUT, src + ".npz"))
+        spec, bins = d["coefficients"], d["bins"]
+        nv = spec.shape[0]
+        for height in (0.1, 5.0):
+            n_peaks = np.zeros(nv, dtype=np.int32)
+            dv = np.full((nv, MAXP), np.nan)
+            fv = np.full((nv, MAXP), np.nan)
+            dc = np.full((nv, len(cutoffs)), np.nan)
+            fc = np.full((nv, len(cutoffs)), np.nan)
+            for i in range(nv):
+                dd, ff = find_spectrum_peaks(spec[i], bins, height=height, regularized=regularized)
+                assert len(dd) <= MAXP
+                n_peaks[i] = len(dd)
+                dv[i, :len(dd)] = dd
+                fv[i, :len(dd)] = ff
+                dc[i], fc[i] = apply_cutoffs(dd, ff, cutoffs)
+            name = f"g9_spectrum_{src[3:]}_h{height:g}".replace(".", "p")
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), spectrum=spec, bins=bins, height=height,
+                                regularized=np.array(regularized), n_peaks=n_peaks, d_values=dv, f_values=fv,
+                                cutoffs=np.array(cutoffs), d_cut=dc, f_cut=fc, **_versions())
+            print(f"{name}: peaks/voxel mean {n_peaks.mean():.2f} max {n_peaks.max()}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
@@ -270,6 +384,13 @@ if __name__ == "__main__":
         sys.path.insert(0, REF_SRC)
         _install_shims()
         main_g7()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        os.makedirs(OUT, exist_ok=True)
+        main_g9()
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
         sys.dont_write_bytecode = True
@@ -280,3 +401,4 @@ if __name__ == "__main__":
         main()
         main_g7()
         main_g8()
+        main_g9()

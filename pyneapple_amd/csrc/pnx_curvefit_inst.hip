@@ -56,22 +56,25 @@ template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const Curvefi
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }
 
-// Built per model: all parameters free (FD or analytic Jacobian) and one or two fixed parameters (analytic, like the
-// reference: curvefit.py:274-288), each without and with the T1 / STEAM factor.
+// Built per model: all parameters free (FD or analytic Jacobian) and every proper subset size of fixed parameters
+// (N = 1 .. NP - 1 free, analytic Jacobian like the reference: curvefit.py:274-288, models/base.py:145-230 allow any
+// subset), each without and with the T1 / STEAM factor.  WHICH parameters are free is run-time data (free_idx / fixed_idx).
+template <int MODEL, bool T1, int N> static int launch_fixed(int n_free, const CurvefitArgs &args, int cus, hipStream_t st) {
+    if constexpr (N >= 1) {
+        if (n_free == N) return launch_pv<MODEL, N, false, T1>(args, cus, st);
+        return launch_fixed<MODEL, T1, N - 1>(n_free, args, cus, st);
+    } else {
+        return set_error(PNX_ERR_INVALID, "model %d%s: %d free parameters", MODEL, T1 ? "+T1" : "", n_free);
+    }
+}
+
 template <int MODEL, bool T1> static int launch_t1(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {
     constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
     if (n_free == NP) {
         if (jac_mode == PNX_JAC_FD) return launch_pv<MODEL, NP, true, T1>(args, cus, st);
         return launch_pv<MODEL, NP, false, T1>(args, cus, st);
     }
-    if constexpr (NP >= 2) {
-        if (n_free == NP - 1) return launch_pv<MODEL, NP - 1, false, T1>(args, cus, st);
-    }
-    if constexpr (NP >= 3) {
-        if (n_free == NP - 2) return launch_pv<MODEL, NP - 2, false, T1>(args, cus, st);
-    }
-    return set_error(PNX_ERR_UNSUPPORTED, "model %d%s with %d free parameters is not built (built: %d, %d and %d: at most two "
-                     "fixed parameters)", MODEL, T1 ? "+T1" : "", n_free, NP, NP - 1, NP - 2);
+    return launch_fixed<MODEL, T1, NP - 1>(n_free, args, cus, st);
 }
 
 template <int MODEL> static int launch_model(int n_free, int jac_mode, const CurvefitArgs &args, int cus, hipStream_t st) {

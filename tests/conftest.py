@@ -78,7 +78,18 @@ def check_g7(r, d, kw, amp):
 
 
 NNLS_FIXTURES = ["g4_nnls_250_r2", "g4_nnls_250_r1", "g4_nnls_250_r3", "g4_nnls_50_r2", "g4_nnls_50_r0",
-                 "g4_nnls_250_r2_maxiter20"]
+                 "g4_nnls_250_r2_maxiter20", "g9_nnls_250_r0"]  # g9_nnls_250_r0: the reference's default reg_order=0
+
+
+def many_fixed_cases():
+    """(fixture, kernel model, free idx, fixed idx, fixed maps (n_fixed, n_vox), extra kwargs): more than two per-pixel
+    fixed parameters -- SegmentedFitter's second step with every diffusivity carried over (fitters/segmented.py:198-225)."""
+    d = load_golden("g9_tri_s0_fixed_D1_D2_D3")
+    yield d, "tri_s0", [0, 2, 5], [1, 3, 4], np.stack([d["fixed_D1"], d["fixed_D2"], d["fixed_D3"]]), {}
+    d = load_golden("g9_tri_full_fixed_D1_D2_D3")
+    yield d, "tri_full", [0, 2, 4], [1, 3, 5], np.stack([d["fixed_D1"], d["fixed_D2"], d["fixed_D3"]]), {}
+    d = load_golden("g9_tri_fixed_4_of_5")
+    yield d, "tri_reduced", [0], [1, 2, 3, 4], np.stack([d["fixed_D1"], d["fixed_f2"], d["fixed_D2"], d["fixed_D3"]]), {}
 
 
 def golden_p0_bounds(d):

@@ -255,11 +255,25 @@ def test_two_fixed_parameters_match_reference_golden(gpu):
         assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-8
         e = pcov_norm_err(r["pcov"][d["sigma"] > 0], d["pcov"][d["sigma"] > 0])
         assert np.median(e) < 1e-6
-    # three fixed parameters are not built: loud error, no fallback
+
+
+def test_three_and_four_fixed_parameters_match_reference_golden(gpu):
+    """Any proper subset may be fixed (models/base.py:145-230): tri S0 and tri full with D1, D2, D3 from a previous
+    step (fitters/segmented.py:198-225: N = 3 of 6), tri reduced with everything but f1 fixed (N = 1 of 5)."""
+    from conftest import many_fixed_cases
+
+    for d, model, free, fixed_idx, fv, kw in many_fixed_cases():
+        r = gpu.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                         fixed_idx=fixed_idx, fixed_vals=fv, jac="analytic", **kw)
+        assert (r["status"] > 0).all() and d["success"].all()
+        assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-8
+        e = pcov_norm_err(r["pcov"][d["sigma"] > 0], d["pcov"][d["sigma"] > 0])
+        assert np.median(e) < 1e-6
+    # scalar (shared) fixed values take the same path
     d = load_golden("g8_tri_fixed_D2_D3")
-    with pytest.raises(Exception, match="not built"):
-        gpu.curvefit("tri_reduced", d["bvalues"], d["y"], d["p0_vals"][[0, 1]], d["lo_vals"][[0, 1]], d["hi_vals"][[0, 1]],
+    r = gpu.curvefit("tri_reduced", d["bvalues"], d["y"], d["p0_vals"][[0, 1]], d["lo_vals"][[0, 1]], d["hi_vals"][[0, 1]],
                      fixed_idx=[2, 3, 4], fixed_vals=np.array([0.3, 0.005, 0.001]), jac="analytic")
+    assert r["popt"].shape == (2, len(d["y"])) and np.isfinite(r["cost"]).all()
 
 
 def test_t1_fixed_matches_reference_golden(gpu):

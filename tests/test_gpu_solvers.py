@@ -162,7 +162,7 @@ def test_xtol_gtol_solver_kwargs_reach_the_kernel(gpu, oracle):
         st = np.asarray(s.diagnostics_["status"])
         assert (st == ref["status"]).mean() > 0.995
         assert (np.asarray(s.diagnostics_["nfev"]) == ref["nfev"]).mean() > 0.99
-        assert (st != np.asarray(default.diagnostics_["status"])).mean() > 0.2  # the tolerance really took effect
+        assert (st != np.asarray(default.diagnostics_["status"])).mean() > 0.05  # the tolerance really took effect
         got = np.stack([s.params_[n] for n in names])
         rel = np.abs(got - ref["popt"]) / np.maximum(np.abs(ref["popt"]), 1e-300)
         assert (rel.max(axis=0) <= 1e-4).mean() >= 0.99

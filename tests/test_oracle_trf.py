@@ -5,7 +5,8 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
+from conftest import (CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, many_fixed_cases,
+                      pcov_norm_err, rel_err)
 
 RTOL = 1e-4  # BASELINE.json north_star: rtol=1e-4 (fp64) per parameter
 
@@ -68,6 +69,15 @@ def test_oracle_two_fixed_params_golden(oracle):
                             fixed_idx=fixed_idx, fixed_vals=fv, jac="analytic", **kw)
         assert (r["status"] > 0).all() and d["success"].all()
         assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-9
+
+
+def test_oracle_three_and_four_fixed_params_golden(oracle):
+    for d, model, free, fixed_idx, fv, kw in many_fixed_cases():
+        r = oracle.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                            fixed_idx=fixed_idx, fixed_vals=fv, jac="analytic", **kw)
+        assert (r["status"] > 0).all() and d["success"].all()
+        assert list(d["free_names"]) == [str(d["all_param_names"][i]) for i in free]
+        assert rel_err(r["popt"].T, d["popt"]).max() <= 1e-8
 
 
 def _scipy_fit(fun, b, y, p0, lo, hi, max_nfev=250, tol=1e-8):
@@ -143,3 +153,31 @@ def test_oracle_failure_sentinels(oracle):
     # max_nfev exhausted -> status 0, p0 returned (SciPy raises RuntimeError, reference returns p0)
     r2 = oracle.curvefit("bi_reduced", b, y[[0]], p0, lo, hi, max_nfev=2)
     assert r2["status"][0] == 0 and np.array_equal(r2["popt"][:, 0], p0) and r2["nfev"][0] == 2
+
+
+def test_scipy_vs_oracle_disagreement_rate_on_noisy_triexp(oracle):
+    """The evidence behind the GPU suite's ">= 99.5 % of a large seeded set within rtol 1e-4" threshold
+    (tests/test_gpu_curvefit.py): SciPy itself, called the way the reference calls it (curvefit.py:295-306), and the
+    oracle disagree beyond 1e-4 on a fraction of a per cent of fresh noisy triexp voxels -- exp() differs in the last
+    ulp between libm and NumPy, a discrete TRF decision flips, and a weakly determined voxel ends at an EQUALLY GOOD
+    point a little further along its valley.  Every voxel has the same cost to 1e-6 relative (measured: 0.27 % beyond
+    1e-4, worst cost difference 1.6e-7 -- the scale of ftol = 1e-8 times a few iterations)."""
+    from pyneapple_amd import synth
+
+    def tri(x, f1, D1, f2, D2, D3):
+        return f1 * np.exp(-x * D1) + f2 * np.exp(-x * D2) + (1 - f1 - f2) * np.exp(-x * D3)
+
+    n = 1500
+    b, y, _ = synth.make_numpy("tri_reduced", n, 32, sigma=0.01, seed=20261004)
+    _, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    r = oracle.curvefit("tri_reduced", b, y, p0, lo, hi, n_threads=4)
+    fits = [_scipy_fit(tri, b, y[i], p0, lo, hi) for i in range(n)]
+    ref = np.array([f[0] for f in fits])
+    ok = np.array([f[1] for f in fits])
+    assert ((r["status"] > 0) == ok).all()
+    worst = rel_err(r["popt"].T, ref).max(axis=1)
+    off = worst > RTOL
+    assert off.mean() <= 0.01, f"{off.mean():.4f} of the voxels beyond rtol 1e-4"   # measured: ~0.2 %
+    assert np.median(worst) < 1e-6
+    cost_ref = 0.5 * ((tri(b[None, :], *ref.T[:, :, None]) - y) ** 2).sum(axis=1)
+    assert (np.abs(r["cost"] - cost_ref) <= 1e-6 * cost_ref)[ok].all()               # equally good minima, every voxel
