@@ -11,8 +11,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "libpnx_hip.so")
+# PNX_VARIANT=name builds a kernel-variant experiment beside the product library (libpnx_hip.name.so, own object dir);
+# load it with PNX_LIB=<path> (pyneapple_amd/_lib.py)
+_VARIANT = os.environ.get("PNX_VARIANT", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + _VARIANT if _VARIANT else ""))
+LIB = os.path.join(HERE, f"libpnx_hip.{_VARIANT}.so" if _VARIANT else "libpnx_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -22,6 +22,10 @@ struct NnlsPlanData {
     double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
     size_t mglob_stride = 0;  // doubles per wave
     int n_waves = 0;          // persistent waves the scratch was sized for
+    int n_blocks = 0;         // persistent workgroups (fast path: 8 waves each)
+    bool fast = false;        // <= 32 measurements and a banded Toeplitz regulariser: LDS-resident basis kernel
+    double rc[5] = {0, 0, 0, 0, 0};  // reg[i][j] = rc[j - i + 2]
+    int rhb = 0;
     unsigned long long *queue = nullptr;
 };
 
