@@ -29,7 +29,7 @@ NNLS_FLAGS = os.environ.get("PNX_NNLS_FLAGS", "").split()  # e.g. -DPNX_NNLS_GBA
 # measured on, and bench.py only replays counters whose stamp matches the sources it is running
 SOURCE_GROUPS = {
     "curvefit": ["pnx_curvefit_kernel.hpp", "pnx_curvefit_inst.hip"],
-    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp"],
+    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp", "pnx_nnls_qr.hip"],
     "sweep": ["pnx_sweep.hip"],
 }
 
@@ -50,7 +50,8 @@ def source_ids() -> dict:
 
 
 def _units():
-    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_sweep.o", "pnx_sweep.hip", []),
+    units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_nnls_qr.o", "pnx_nnls_qr.hip", NNLS_FLAGS),
+             ("pnx_sweep.o", "pnx_sweep.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
         units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}", *CURVEFIT_FLAGS]))

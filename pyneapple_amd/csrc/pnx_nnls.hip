@@ -23,19 +23,6 @@
 //     4 positions per lane, and is broadcast with v_readlane / moved with DPP instead of LDS round trips.
 //   * G (n_bins x 256 fp64 = 0.5 MB, zero padded) and B stay L2 resident; the dual update streams p rows of G per
 //     iteration, two 16-byte loads per lane and row, 4 rows in flight.
-//
-// Two instantiations of one kernel template:
-//   nnls_kernel<false>  general path: any basis (<= 128 measurements), any regulariser; one wave per workgroup; the dual
-//       w = A^T y - G[:,P] x_P streams p rows of G (2 KB each) from L2 per outer iteration.  PMC (profiles/r01_j_pmc_nnls.txt):
-//       88 k L1 accesses per voxel per CU against 132 k cycles per voxel -- the per-CU vector-memory pipe (one 64-byte access
-//       per clock) is what bounds it, cutting VALU instructions alone changes nothing (measured, round 2).
-//   nnls_kernel<true>   fast path for what the reference builds (model_functions/nnls.py:46-85): <= 32 measurements and a
-//       regulariser that is a square banded Toeplitz matrix R with zero boundary (orders 1-3; order 0 is "no regulariser").
-//       A workgroup is 8 waves that share ONE copy of the basis B in LDS (64 KB); every wave still owns one voxel.  The dual is
-//       evaluated in residual form  w = B^T (y - B_P x_P) - R^T (R x)  entirely out of LDS: column reads of B for the
-//       residual, 32 row reads for B^T r (256 B / clk LDS instead of 64 B / clk L1), and two 3- or 5-tap stencils through
-//       a bin-ordered LDS scratch for the regulariser.  Cost independent of the passive-set size, no L2 traffic.
-//       A^T y = B^T y comes from the same LDS copy (no ATY round trip through HBM).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -79,16 +66,9 @@ struct NnlsArgs {
     unsigned long long *queue;
     long long n_vox;
     int n_meas, n_bins, n_reg, max_iter;
-    double rc[5];  // fast path: R[i][j] = rc[j - i + 2] for |j - i| <= 2 (mu included), zero outside
-    int rhb;       // half bandwidth of R (1 or 2)
+    double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] for |j - i| <= 2 (mu included), zero outside
+    int rhb;       // its half bandwidth (1 or 2); 0: general regulariser, rows of RT are used instead
 };
-
-// fast path LDS geometry: B as 32 rows of kBStride doubles (row stride 258: a column read B[m][j], lane = m, is
-// cheap, a row read is two ds_read_b128 per lane), then per wave the packed rows of M and a scratch area
-constexpr int kFastWaves = 8;
-constexpr int kFastMeas = 32;
-constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; column reads (lane = m) are 2-way bank conflicted
-constexpr int kScratch = 288;  // doubles: bc[64] | position staging xs[128] + ps[128] | rb[32] at 192 | bin-ordered xbuf[2 + 256 + 2]
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
 
@@ -145,22 +125,10 @@ __device__ inline int wave_min_i(int v) {
 }
 
 // acc += a * b on the lanes of `mask` only (wave-uniform mask).  One VALU instruction: the mask goes through EXEC on the
-// scalar unit instead of a v_cmp + two v_cndmask per fp64 value (the kernel is VALU-issue bound).  EXEC is saved and
-// restored inside the statement, so the compiler never sees it changed.
+// scalar unit instead of a v_cmp + two v_cndmask per fp64 value.  EXEC is saved and restored inside the statement, so the
+// compiler never sees it changed.
 #ifndef PNX_NNLS_ASM_MASK
 #define PNX_NNLS_ASM_MASK 1
-#endif
-#ifndef PNX_NNLS_BALLOT_SKIP
-#define PNX_NNLS_BALLOT_SKIP 1
-#endif
-#ifndef PNX_NNLS_FAST_SCALAR
-#define PNX_NNLS_FAST_SCALAR 1
-#endif
-#ifndef PNX_NNLS_KU_GEN
-#define PNX_NNLS_KU_GEN 4  // LDS rows in flight per step of the column pass (general path)
-#endif
-#ifndef PNX_NNLS_KU_MG
-#define PNX_NNLS_KU_MG 4   // LDS columns in flight per step of l = M g (general path)
 #endif
 __device__ inline void fma_on(double &acc, double a, double b, unsigned long long mask) {
 #if PNX_NNLS_ASM_MASK
@@ -183,20 +151,13 @@ __device__ inline double rsqrt_nr(double a) {
     return y;
 }
 
-// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1}: one row of G or B is two 16-byte loads per lane.
-// (both paths: one row of B in LDS is two ds_read_b128 per lane as well -- 256 B / clk, a ds_read2st64_b64 gets half of that)
-template <bool FAST> __device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
-// Lanes of one wave talk through LDS without barriers (the hardware executes a wave's LDS instructions in order).  The
-// COMPILER, however, reasons per thread: "I store xbuf[lane] and later load xbuf[lane + 1]: no alias, the load may move
-// up".  lds_order() is a compiler-only fence (no instruction) that pins the program order of memory operations.
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-typedef int __attribute__((may_alias)) lds_int;  // int view of the double scratch (the accesses really do alias)
 __device__ inline void wave_sync() {
-    // one wave: LDS and vector-memory instructions issue in order, so "everything I wrote is visible to my other lanes"
-    // is a wait, not a barrier (a workgroup barrier would deadlock the fast path: its 8 waves run independent voxels)
+    // one wave per workgroup: "everything I wrote (LDS / my global scratch slab) is visible to my other lanes" is a wait
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1}: one row of G or B is two 16-byte loads per lane.
+__device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
 
 // ---- position-indexed register vectors (position i lives in lane i & 63, slot i >> 6) --------------
 template <int S> struct SlotTag { static constexpr int value = S; };
@@ -259,8 +220,8 @@ __device__ inline void shift_down_i(const int (&a)[kSlots], int (&out)[kSlots], 
 
 // out[s] (k = lane + 64 s) = sum_{i >= k} va_i * M[i][k]  (and the same with vb when TWO): one sweep over the
 // packed lower-triangular M, every row read contiguously; va_i / vb_i are broadcast with v_readlane.
-template <bool TWO, int kU>
-__device__ inline void col_pass(const double *Mlds, double *bc, const double *Mg, int p, int lane, const double (&va)[kSlots],
+template <bool TWO>
+__device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int lane, const double (&va)[kSlots],
                                 const double (&vb)[kSlots], double (&oa)[kSlots], double (&ob)[kSlots]) {
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -269,28 +230,18 @@ __device__ inline void col_pass(const double *Mlds, double *bc, const double *Mg
     }
     const int p_lds = p < kLdsRows ? p : kLdsRows;
     // branch-free body (clamped address, masked product) so that the unrolled steps keep their LDS reads in flight
-    lds_order();
+    extern __shared__ double dyn_lds[];  // the kernel's dynamic LDS (same base as Mlds): rows of M, then bc[64]
+    double *bc = dyn_lds + kLdsTri;
     bc[lane] = va[0];  // broadcast reads (one LDS instruction) instead of two v_readlane per value: the kernel is VALU bound
-    lds_order();
-    // eight rows per step, every LDS read of the step issued before its first FMA: with two waves per SIMD on the fast
-    // path there is no other wave to hide a read-wait-FMA chain per row (~110 cycles each, measured)
-    for (int i0 = 0; i0 < p_lds; i0 += kU) {
-        double a[kU], b[kU], m0[kU];
-#pragma unroll
-        for (int r = 0; r < kU; ++r) {
-            const int i = i0 + r < p_lds ? i0 + r : p_lds - 1;  // ragged last step: a valid row, masked off below
-            a[r] = bc[i];
-            b[r] = TWO ? rl(vb[0], i) : 0.0;
-            // lanes beyond the row read on into the following rows / the broadcast buffer (inside the allocation:
-            // tri(47) + 63 < kLdsTri + 64); their product is masked
-            m0[r] = Mlds[tri(i) + lane];
-        }
-#pragma unroll
-        for (int r = 0; r < kU; ++r) {
-            const unsigned long long on = i0 + r < p_lds ? (2ull << (i0 + r)) - 1 : 0ull;  // lanes 0 .. i
-            fma_on(oa[0], a[r], m0[r], on);
-            if (TWO) fma_on(ob[0], b[r], m0[r], on);
-        }
+    for (int i = 0; i < p_lds; ++i) {
+        const double a = bc[i];
+        const double b = TWO ? rl(vb[0], i) : 0.0;
+        // lanes beyond the row read on into the following rows / the broadcast buffer (inside the allocation: tri(47) + 63 <
+        // kLdsTri + 64); their product is masked
+        const double m0 = Mlds[tri(i) + lane];
+        const unsigned long long on = (2ull << i) - 1;  // lanes 0 .. i
+        fma_on(oa[0], a, m0, on);
+        if (TWO) fma_on(ob[0], b, m0, on);
     }
     // overflow rows (global scratch): four rows' loads are issued before any of them is consumed
     auto one = [&](int i, auto S) {
@@ -335,65 +286,11 @@ __device__ inline void col_pass(const double *Mlds, double *bc, const double *Mg
     for_pos4(kLdsRows, p, four, one);
 }
 
-// ---- fast path: products with the LDS-resident basis ------------------------------------------------
-// out[s] (bin binof(lane, s)) = sum_m B[m][bin] * v[m], v read from LDS (32 doubles at `v`, uniform address broadcast reads)
-__device__ __forceinline__ void bt_times(const double *Bl, const double *v, int lane, double (&out)[kSlots]) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) out[s] = 0;
-#pragma unroll 2
-    for (int m = 0; m < kFastMeas; m += 4) {
-        const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
-        const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
-        const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double *row = Bl + (m + r) * kBStride + 2 * lane;
-            const double2 b0 = *reinterpret_cast<const double2 *>(row);
-            const double2 b1 = *reinterpret_cast<const double2 *>(row + 128);
-            out[0] = fma(b0.x, vv[r], out[0]);
-            out[1] = fma(b0.y, vv[r], out[1]);
-            out[2] = fma(b1.x, vv[r], out[2]);
-            out[3] = fma(b1.y, vv[r], out[3]);
-        }
-    }
-}
-// lanes 0..31 (and, duplicated, 32..63): (B_P x_P)[m], m = lane & 31, from the staged position arrays xs / ps (zero padded
-// to an even count); positions >= 128 (rare) come straight from the registers
-__device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs, const lds_int *ps, int p, int lane,
-                                    const double (&x)[kSlots], const int (&pidx)[kSlots]) {
-    const int m = lane & 31, h = lane >> 5;
-    const double *Bm = Bl + m * kBStride;
-    double a0 = 0, a1 = 0;
-    const int pl = p < 128 ? p : 128;
-    const int p2 = (pl + 1) & ~1;  // staged positions rounded up to a pair (the pad entry holds x = 0)
-    int i = h;
-    for (; i + 2 < p2; i += 4) {  // half wave h takes positions h, h + 2, ...: two of them per step
-        const double x0 = xs[i], x1 = xs[i + 2];
-        const int j0 = ps[i], j1 = ps[i + 2];
-        a0 = fma(x0, Bm[j0], a0);
-        a1 = fma(x1, Bm[j1], a1);
-    }
-    if (i < p2) a0 = fma(xs[i], Bm[ps[i]], a0);
-    double acc = a0 + a1;
-    acc += __shfl_xor(acc, 32);
-    for (int k = 128; k < p; ++k) {
-        const double xk = k < 192 ? rl(x[2], k & 63) : rl(x[3], k & 63);
-        const int jk = k < 192 ? __builtin_amdgcn_readlane(pidx[2], k & 63) : __builtin_amdgcn_readlane(pidx[3], k & 63);
-        acc = fma(xk, Bm[jk], acc);
-    }
-    return acc;
-}
-// stage x / pidx of positions < min(p, 128) (zeros up to the next multiple of 64 + 1) for b_times_xp
-__device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kSlots], const int (&pidx)[kSlots]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int i = lane + kW * s;
-        if (kW * s <= p) {  // wave uniform; the slot that holds position p (the zero pad of an odd count) is written too
-            xs[i] = i < p ? x[s] : 0.0;
-            ps[i] = i < p ? pidx[s] : 0;
-        }
-    }
-}
+// Lanes of one wave talk through LDS without barriers (the hardware executes a wave's LDS instructions in order).  The
+// COMPILER, however, reasons per thread: "I store xbuf[lane] and later load xbuf[lane + 1]: no alias, the load may move
+// up".  lds_order() is a compiler-only fence (no instruction) that pins the program order of memory operations.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 // t = R v and u = R^T t through the bin-ordered scratch (zero boundary: R is n x n, R[i][j] = c[j - i + 2]);
 // v by position (x, pidx, p).  Returns u by bin in `u`, and sum t^2 of this lane's bins in *tt.  A lane owns the bin
 // pairs (2 l, 2 l + 1) and (128 + 2 l, 129 + 2 l): three 16-byte reads per pair bring the pair and its two neighbours
@@ -437,7 +334,7 @@ __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], in
     double acc = 0;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
-        t[s] = (binof<true>(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
+        t[s] = (binof(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
         acc = fma(t[s], t[s], acc);
     }
     if (tt) *tt = acc;
@@ -457,34 +354,17 @@ __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], in
 #define STAMP(k) do {} while (0)
 #endif
 
-template <bool FAST>
-__global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const NnlsArgs A) {
+__global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const NnlsArgs A) {
 #ifdef PNX_NNLS_STAMP
-    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    extern __shared__ double dyn_lds[];
-    const int lane = threadIdx.x & (kW - 1);
-    const int wave = FAST ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M, then bc[64]
+    double *bc = Mlds + kLdsTri;      // broadcast buffer: position-indexed values of slot 0, read with a uniform address
+    const int lane = threadIdx.x;
+    double *Mg = A.Mglob + (size_t)blockIdx.x * kGlobTri;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
     const int m_total = nm + nreg;
-    // general: [M rows][bc 64];  fast: [B 32 x kBStride][wave 0: M rows, scratch][wave 1: ...]
-    double *Bl = dyn_lds;
-    double *Mlds = FAST ? dyn_lds + kFastMeas * kBStride + wave * (kLdsTri + kScratch) : dyn_lds;
-    double *bc = Mlds + kLdsTri;  // broadcast buffer (first 64 doubles of the scratch): position-indexed values of slot 0, read with a uniform address
-    double *Mg = A.Mglob + (size_t)(FAST ? blockIdx.x * kFastWaves + wave : blockIdx.x) * kGlobTri;
-    if constexpr (FAST) {
-        for (int e = threadIdx.x; e < kFastMeas * kBStride; e += kFastWaves * kW) {
-            const int m = e / kBStride, j = e - m * kBStride;
-            Bl[e] = (m < nm && j < kNnlsMaxBins) ? A.Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
-        }
-        __syncthreads();  // the only workgroup barrier: from here on the waves never meet again
-    }
-    // fast path scratch views (alias the broadcast buffer; every use rewrites what it reads)
-    double *xs = bc + kW;                                   // [128] staged x by position
-    lds_int *ps = reinterpret_cast<lds_int *>(bc + kW + 128);  // [128] staged bin index by position
-    double *rb = bc + 192 + 64;                             // [32] residual of the measurements, behind the staging area
-    double *xbuf = bc;                                      // [2 + 256 + 2] x (then R x) in bin order, zero padded
 
     for (;;) {
         unsigned long long vq = 0;
@@ -512,14 +392,7 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
         finite = __all(finite ? 1 : 0) != 0;
         double aty[kSlots] = {0, 0, 0, 0}, w[kSlots], z[kSlots] = {0, 0, 0, 0};
         bool inP[kSlots] = {false, false, false, false};
-        if constexpr (FAST) {
-            // A^T y = B^T y out of the LDS copy of B (y broadcast through the scratch)
-            lds_order();
-            if (lane < kFastMeas) rb[lane] = (lane < nm && finite) ? yreg[0] : 0.0;
-            lds_order();
-            bt_times(Bl, rb, lane, aty);
-            lds_order();
-        } else if (finite && A.aty) {
+        if (finite && A.aty) {
             const double *ar = A.aty + (size_t)vox * kNnlsMaxBins + 2 * lane;
             const double2 a0 = *reinterpret_cast<const double2 *>(ar);
             const double2 a1 = *reinterpret_cast<const double2 *>(ar + 128);
@@ -547,88 +420,62 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
         STAMP(0);
 
         while (status == 1 && p < n && p < m_total) {
-            if constexpr (FAST) {
-                // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
-                stage_positions(xs, ps, p, lane, x, pidx);
-                lds_order();
-                const double bx = b_times_xp(Bl, xs, ps, p, lane, x, pidx);
-                if (lane < kFastMeas) rb[lane] = lane < nm ? yreg[0] - bx : 0.0;
-                lds_order();
-                STAMP(9);
-                bt_times(Bl, rb, lane, w);
-                lds_order();
-                STAMP(10);
-                if (nreg) {
-                    double u[kSlots];
-                    reg_terms<true>(xbuf, A.rc, A.rhb, n, p, lane, x, pidx, u, nullptr);
-#pragma unroll
-                    for (int s = 0; s < kSlots; ++s) w[s] -= u[s];
-                }
-            } else {
             // ---- dual w = A^T y - G[:,P] x_P on the zero set: p rows of G (L2 resident), kGBatch in flight
-    #pragma unroll
-                for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
-                // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
-                // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
-                bc[lane] = x[0];  // the kernel is VALU-issue bound: x_pos comes back through an LDS broadcast read, not 2 readlanes
-    #pragma unroll
-                for (int sl = 0; sl < kSlots; ++sl) {
-                    if (p <= sl * kW) break;  // wave-uniform
-                    const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
-                    int l0 = 0;
-                    for (; l0 + kGBatch <= cnt; l0 += kGBatch) {  // full batches: no clamping, no masking
-                        double2 ga[kGBatch], gb[kGBatch];
-                        double xs[kGBatch];
-    #pragma unroll
-                        for (int u = 0; u < kGBatch; ++u) {
-                            const int col = __builtin_amdgcn_readlane(pidx[sl], l0 + u);
-                            xs[u] = sl == 0 ? bc[l0 + u] : rl(x[sl], l0 + u);
-                            const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
-                            ga[u] = *reinterpret_cast<const double2 *>(gc);
-                            gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
-#ifdef PNX_NNLS_EXP_DOUBLE_G
-                            {  // experiment: the same row once more from another address range (G is followed by padding rows)
-                                const double *gd = A.G + (size_t)((col + 128) & 255) * kNnlsMaxBins + 2 * lane;
-                                double2 d0 = *reinterpret_cast<const double2 *>(gd), d1 = *reinterpret_cast<const double2 *>(gd + 128);
-                                asm volatile("" ::"v"(d0.x), "v"(d0.y), "v"(d1.x), "v"(d1.y));
-                            }
-#endif
-                        }
-    #pragma unroll
-                        for (int u = 0; u < kGBatch; ++u) {
-                            w[0] -= ga[u].x * xs[u];
-                            w[1] -= ga[u].y * xs[u];
-                            w[2] -= gb[u].x * xs[u];
-                            w[3] -= gb[u].y * xs[u];
-                        }
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
+            // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
+            // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
+            bc[lane] = x[0];  // the kernel is VALU-issue bound: x_pos comes back through an LDS broadcast read, not 2 readlanes
+#pragma unroll
+            for (int sl = 0; sl < kSlots; ++sl) {
+                if (p <= sl * kW) break;  // wave-uniform
+                const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
+                int l0 = 0;
+                for (; l0 + kGBatch <= cnt; l0 += kGBatch) {  // full batches: no clamping, no masking
+                    double2 ga[kGBatch], gb[kGBatch];
+                    double xs[kGBatch];
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        const int col = __builtin_amdgcn_readlane(pidx[sl], l0 + u);
+                        xs[u] = sl == 0 ? bc[l0 + u] : rl(x[sl], l0 + u);
+                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
+                        ga[u] = *reinterpret_cast<const double2 *>(gc);
+                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
                     }
-                    if (l0 < cnt) {  // ragged last batch
-                        double2 ga[kGBatch], gb[kGBatch];
-                        double xs[kGBatch];
-    #pragma unroll
-                        for (int u = 0; u < kGBatch; ++u) {
-                            const bool on = l0 + u < cnt;
-                            const int ll_ = on ? l0 + u : cnt - 1;
-                            const int col = __builtin_amdgcn_readlane(pidx[sl], ll_);
-                            const double xv = rl(x[sl], ll_);
-                            xs[u] = on ? xv : 0.0;
-                            const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
-                            ga[u] = *reinterpret_cast<const double2 *>(gc);
-                            gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
-                        }
-    #pragma unroll
-                        for (int u = 0; u < kGBatch; ++u) {
-                            w[0] -= ga[u].x * xs[u];
-                            w[1] -= ga[u].y * xs[u];
-                            w[2] -= gb[u].x * xs[u];
-                            w[3] -= gb[u].y * xs[u];
-                        }
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        w[0] -= ga[u].x * xs[u];
+                        w[1] -= ga[u].y * xs[u];
+                        w[2] -= gb[u].x * xs[u];
+                        w[3] -= gb[u].y * xs[u];
+                    }
+                }
+                if (l0 < cnt) {  // ragged last batch
+                    double2 ga[kGBatch], gb[kGBatch];
+                    double xs[kGBatch];
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        const bool on = l0 + u < cnt;
+                        const int ll_ = on ? l0 + u : cnt - 1;
+                        const int col = __builtin_amdgcn_readlane(pidx[sl], ll_);
+                        const double xv = rl(x[sl], ll_);
+                        xs[u] = on ? xv : 0.0;
+                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
+                        ga[u] = *reinterpret_cast<const double2 *>(gc);
+                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGBatch; ++u) {
+                        w[0] -= ga[u].x * xs[u];
+                        w[1] -= ga[u].y * xs[u];
+                        w[2] -= gb[u].x * xs[u];
+                        w[3] -= gb[u].y * xs[u];
                     }
                 }
             }
 #pragma unroll
             for (int s = 0; s < kSlots; ++s)
-                if (inP[s] || binof<FAST>(lane, s) >= n) w[s] = -INFINITY;
+                if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
             STAMP(1);
 
             bool accepted = false;
@@ -645,7 +492,7 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                 int bj = kNone;
 #pragma unroll
                 for (int s = kSlots - 1; s >= 0; --s)
-                    if (w[s] == best) bj = binof<FAST>(lane, s);
+                    if (w[s] == best) bj = binof(lane, s);
                 jmax = wave_min_i(bj);
                 // ---- g = G[P, jmax] (by position), l = M g
                 const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
@@ -669,23 +516,21 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                     // unrolled by hand (the compiler does not unroll loops around v_readlane): four LDS reads in flight,
                     // two accumulators, a quarter of the loop control
                     double acc0 = 0, acc1 = 0;
-                    lds_order();
+                    int k = 0;
                     bc[lane] = g[0];
-                    lds_order();
-                    constexpr int kU = FAST ? 8 : PNX_NNLS_KU_MG;
-                    for (int k0 = 0; k0 < plim; k0 += kU) {
-                        double gk[kU], mk[kU];
-#pragma unroll
-                        for (int r = 0; r < kU; ++r) {
-                            gk[r] = bc[k0 + r];   // k0 + r < 56 < 64: inside the broadcast buffer (lanes >= p hold g = 0)
-                            mk[r] = row0[k0 + r]; // tri(47) + 55 < kLdsTri + 64: inside the allocation; masked below
-                        }
-#pragma unroll
-                        for (int r = 0; r < kU; r += 2) {
-                            // lanes >= k; lanes >= plim accumulate garbage they never use; columns >= plim are masked off
-                            fma_on(acc0, mk[r], gk[r], k0 + r < plim ? ~0ull << (k0 + r) : 0ull);
-                            fma_on(acc1, mk[r + 1], gk[r + 1], k0 + r + 1 < plim ? ~0ull << (k0 + r + 1) : 0ull);
-                        }
+                    for (; k + 4 <= plim; k += 4) {
+                        const double g0 = bc[k], g1 = bc[k + 1], g2 = bc[k + 2], g3 = bc[k + 3];
+                        const double m0 = row0[k], m1 = row0[k + 1], m2 = row0[k + 2], m3 = row0[k + 3];
+                        const unsigned long long on = ~0ull << k;  // lanes >= k; lanes >= plim accumulate garbage they never use
+                        fma_on(acc0, m0, g0, on);
+                        fma_on(acc1, m1, g1, on << 1);
+                        fma_on(acc0, m2, g2, on << 2);
+                        fma_on(acc1, m3, g3, on << 3);
+                    }
+                    for (; k < plim; ++k) {
+                        const double gk = bc[k];
+                        const double m0 = row0[k];  // tri(lane) + k < tri(kLdsRows): always inside the LDS rows
+                        fma_on(acc0, m0, gk, ~0ull << k);
                     }
                     l[0] = mine ? acc0 + acc1 : 0.0;
                 }
@@ -745,29 +590,18 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                 const double lam2 = Gjj - ll;
                 // Gram form: lam^2 = G_jj - |l|^2 carries an absolute rounding error of a few eps*G_jj; below that
                 // floor the column is numerically dependent on the passive set (only happens without regulariser)
-#if PNX_NNLS_FAST_SCALAR
+                // wave-uniform scalar algebra on v_rsq_f64 + Newton instead of the IEEE sqrt / divide expansions
                 const bool indep = lam2 > 64.0 * 2.220446049250313e-16 * Gjj;
                 const double ilam = indep ? rsqrt_nr(lam2) : 0.0;
                 lam = lam2 * ilam;
-                lam = fma(0.5 * ilam, fma(-lam, lam, lam2), lam);  // correctly rounded to within an ulp
+                lam = fma(0.5 * ilam, fma(-lam, lam, lam2), lam);  // sqrt(lam2) to within an ulp
                 const double un = ll > 0 ? ll * rsqrt_nr(ll) : 0.0;
                 bool ok = ((un + lam * 0.01) - un) > 0;  // Lawson-Hanson linear-independence test
                 if (ok) {
                     qn = (atyj - lq) * ilam;
-                    ok = qn > 0;  // ztest = qn / lam, lam > 0
+                    ok = qn > 0;  // ztest = qn / lam with lam > 0
                 }
                 inv_lam = ilam;
-#else
-                lam = lam2 > 64.0 * 2.220446049250313e-16 * Gjj ? sqrt(lam2) : 0.0;
-                const double un = sqrt(ll);
-                bool ok = ((un + lam * 0.01) - un) > 0;  // Lawson-Hanson linear-independence test
-                if (ok) {
-                    qn = (atyj - lq) / lam;
-                    const double ztest = qn / lam;
-                    ok = ztest > 0;
-                }
-                inv_lam = 1.0 / lam;
-#endif
                 if (ok) {
                     accepted = true;
                     break;
@@ -775,7 +609,7 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s)
-                    if (binof<FAST>(lane, s) == jmax) w[s] = 0.0;
+                    if (binof(lane, s) == jmax) w[s] = 0.0;
             }
             STAMP(2);
             if (!accepted) break;
@@ -789,7 +623,7 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                 // current solution (x == z = M_old^T q_old whenever a column enters): z_k = x_k + r_k * qn.  After
                 // every removal z is recomputed from scratch (second sweep below), so nothing drifts.
                 double a1[kSlots], a2[kSlots];
-                col_pass<false, FAST ? 8 : PNX_NNLS_KU_GEN>(Mlds, bc, Mg, p, lane, l, l, a1, a2);
+                col_pass<false>(Mlds, Mg, p, lane, l, l, a1, a2);
                 const double inv = inv_lam;
                 double *rowp = (p < kLdsRows) ? (Mlds + tri(p)) : (Mg + (tri(p) - kLdsTri));
 #pragma unroll
@@ -803,14 +637,14 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                         rowp[k] = inv;
                         z[s] = qn * inv;
                     }
-                    if (binof<FAST>(lane, s) == jmax) inP[s] = true;
+                    if (binof(lane, s) == jmax) inP[s] = true;
                 }
                 put(q, p, qn, lane);
                 put(x, p, 0.0, lane);
                 put_i(pidx, p, jmax, lane);
                 p += 1;
             }
-            wave_sync();
+            __syncthreads();
             STAMP(3);
 
             // ---- inner loop: keep the passive-set solution feasible
@@ -820,7 +654,6 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                     status = 0;
                     break;
                 }
-#if PNX_NNLS_BALLOT_SKIP
                 {
                     // most inner iterations (46 of 64 on the C4 workload) find no z <= 0: one ballot instead of four fp64
                     // divisions and two wave reductions
@@ -834,7 +667,6 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                         break;
                     }
                 }
-#endif
                 double bestT = INFINITY;
                 int bpos = kNone;
 #pragma unroll
@@ -955,11 +787,11 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                                 x[s] = xsh[s];
                                 pidx[s] = psh[s];
                             }
-                            if (binof<FAST>(lane, s) == bin_out) inP[s] = false;
+                            if (binof(lane, s) == bin_out) inP[s] = false;
                         }
                     }
                     p -= 1;
-                    wave_sync();
+                    __syncthreads();
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
@@ -975,54 +807,39 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                 // ---- z = M^T q
                 {
                     double dummy[kSlots];
-                    col_pass<false, FAST ? 8 : PNX_NNLS_KU_GEN>(Mlds, bc, Mg, p, lane, q, q, z, dummy);
+                    col_pass<false>(Mlds, Mg, p, lane, q, q, z, dummy);
                 }
                 STAMP(6);
             }
         }
         STAMP(7);
 
-        // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
+        // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly.  M is dead now: its LDS rows serve as
+        // the bin-ordered scratch that turns x by position into x by bin (one scatter instead of p x 14 select instructions)
+        // and, for the reference's banded regularisers, carries the stencil R x (the generic loop over rows of RT is p
+        // dependent L2 round trips per 64 rows of R: 110 k cycles per voxel, 6 % of the kernel, measured with the stamps)
         double xb[kSlots] = {0, 0, 0, 0};
         double rn;
-        if constexpr (FAST) {
-            if (status == 1) {
-                double tt = 0, dummy[kSlots];
-                reg_terms<false>(xbuf, A.rc, A.rhb, nreg ? n : 0, p, lane, x, pidx, dummy, &tt);  // leaves x in bin order in xbuf
+        if (status == 1) {
+            wave_sync();
+            double *xbuf = Mlds;  // [2 + 256 + 2] <= kLdsTri
+            double tt = 0, dummy[kSlots];
+            reg_terms<false>(xbuf, A.rc, A.rhb, A.rhb ? nreg : 0, p, lane, x, pidx, dummy, &tt);  // leaves x in bin order in xbuf
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof<FAST>(lane, s)];
-                wave_sync();  // the staging area below aliases xbuf
-                stage_positions(xs, ps, p, lane, x, pidx);
-                lds_order();
-                const double bx = b_times_xp(Bl, xs, ps, p, lane, x, pidx);
-                lds_order();
-                const double r = lane < nm ? yreg[0] - bx : 0.0;  // lanes 32..63 duplicate lanes 0..31: nm <= 32 masks them
-                rn = sqrt(wave_sum(fma(r, r, nreg ? tt : 0.0)));
-            } else
-                rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
-        } else {
-            if (status == 1) {
-                for_pos<4>(0, p, [&](int i, auto S) {
-                    constexpr int si = decltype(S)::value;
-                    const int b = __builtin_amdgcn_readlane(pidx[si], i & 63);
-                    const double xv = rl(x[si], i & 63);
-#pragma unroll
-                    for (int s = 0; s < kSlots; ++s)
-                        if (binof<FAST>(lane, s) == b) xb[s] = xv;
-                });
+            for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof(lane, s)];
+            wave_sync();
+            double acc = 0;
+            for (int k = 0; k < nm; ++k) {
+                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
+                const double2 b0 = *reinterpret_cast<const double2 *>(br);
+                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
+                const double fit = wave_sum(b0.x * xb[0] + b0.y * xb[1] + b1.x * xb[2] + b1.y * xb[3]);
+                const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
+                if (lane == 0) acc += (fit - yk) * (fit - yk);
             }
-            if (status == 1) {
-                double acc = 0;
-                for (int k = 0; k < nm; ++k) {
-                    const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
-                    const double2 b0 = *reinterpret_cast<const double2 *>(br);
-                    const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
-                    const double fit = wave_sum(b0.x * xb[0] + b0.y * xb[1] + b1.x * xb[2] + b1.y * xb[3]);
-                    const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
-                    if (lane == 0) acc += (fit - yk) * (fit - yk);
-                }
-                acc = rl(acc, 0);
-                double racc = 0;
+            acc = rl(acc, 0);
+            double racc = tt;
+            if (!A.rhb) {  // general regulariser: rows of reg, 64 at a time
                 for (int i0 = 0; i0 < nreg; i0 += kW) {
                     const int i = i0 + lane;
                     double r = 0;
@@ -1034,14 +851,14 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
                     });
                     racc += r * r;
                 }
-                rn = sqrt(acc + wave_sum(racc));
-            } else
-                rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
-        }
+            }
+            rn = sqrt(acc + wave_sum(racc));
+        } else
+            rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
         double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
-            const int j = binof<FAST>(lane, s);
+            const int j = binof(lane, s);
             if (j < n) cv[j] = xb[s];
         }
         if (lane == 0) {
@@ -1053,7 +870,7 @@ __global__ void __launch_bounds__(FAST ? kFastWaves * kW : kW, FAST ? 2 : PNX_NN
     }
 #ifdef PNX_NNLS_STAMP
     if (lane == 0 && blockIdx.x == 7)
-        printf("STAMP setup=%llu w=%llu (bx=%llu btr=%llu) cand=%llu append=%llu alpha=%llu removal=%llu colpass2=%llu tail=%llu out=%llu\n", seg[0], seg[1], seg[9], seg[10], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7], seg[8]);
+        printf("STAMP setup=%llu w=%llu cand=%llu append=%llu alpha=%llu removal=%llu colpass2=%llu tail=%llu out=%llu\n", seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7], seg[8]);
 #endif
 }
 
@@ -1134,7 +951,7 @@ static size_t nnls_lds_bytes() {
     static const size_t pad = getenv("PNX_NNLS_LDS_PAD") ? (size_t)atoi(getenv("PNX_NNLS_LDS_PAD")) : 0;  // occupancy experiments
     return sizeof(double) * (kLdsTri + kW) + pad;
 }
-static size_t nnls_fast_lds_bytes() { return sizeof(double) * (kFastMeas * kBStride + kFastWaves * (kLdsTri + kScratch)); }
+static_assert(kLdsTri >= 2 + kNnlsMaxBins + 2, "the epilogue's bin-ordered scratch aliases the LDS rows of M");
 
 // Is reg what model_functions/nnls.py:46-85 builds for orders 1-3: square, R[i][j] = c[j - i] inside a band of half width
 // <= 2 and exactly zero outside?  Then the regulariser is five numbers and the fast kernel applies it as a stencil.
@@ -1153,6 +970,7 @@ static bool toeplitz_band(const double *reg, int n_reg, int n_bins, double (&c)[
     return any;
 }
 
+
 int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                    int device, int cus) {
     P->device = device;
@@ -1160,7 +978,13 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     P->n_meas = n_meas;
     P->n_bins = n_bins;
     P->n_reg = n_reg;
-    P->fast = !getenv("PNX_NNLS_GENERAL") && n_meas <= kFastMeas && toeplitz_band(reg, n_reg, n_bins, P->rc, &P->rhb);
+    if (!toeplitz_band(reg, n_reg, n_bins, P->rc, &P->rhb) || getenv("PNX_NNLS_GENERIC_REG")) P->rhb = 0;
+    {   // reg_order = 0 (the reference's default) is an all-zero matrix: without regulariser rows the Gram form squares a
+        // condition number of ~1e16 -- those fits go through the QR-based kernel
+        bool zero = true;
+        for (size_t i = 0; i < (size_t)n_reg * n_bins && zero; ++i) zero = reg[i] == 0.0;
+        P->qr = zero && n_meas <= 64 && !getenv("PNX_NNLS_NO_QR");
+    }
     const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)kNnlsMaxBins * kNnlsMaxBins;
     for (size_t i = 0; i < nb; ++i)
         if (!std::isfinite(basis[i])) return set_error(PNX_ERR_INVALID, "basis contains non-finite values");
@@ -1186,23 +1010,14 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     hipLaunchKernelGGL(gram_kernel, dim3((n_bins + 63) / 64, n_bins), dim3(64), 0, 0, P->B, P->RT, n_meas, n_bins,
                        n_reg, P->G);
     PNX_HIPN(hipGetLastError());
-    // persistent grid: as many workgroups as fit (LDS bound), one overflow slab per wave
+    // persistent grid: as many single-wave workgroups as fit (LDS bound), one scratch slab each
+    PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
     int occ = 0;
-    if (P->fast) {
-        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_fast_lds_bytes()));
-        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<true>, kFastWaves * kW, nnls_fast_lds_bytes()));
-        if (occ < 1) return set_error(PNX_ERR_HIP, "nnls fast kernel does not fit on a CU");
-        P->n_blocks = occ * cus;
-        P->n_waves = P->n_blocks * kFastWaves;
-    } else {
-        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
-        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<false>, kW, nnls_lds_bytes()));
-        if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
-        P->n_blocks = P->n_waves = occ * cus;
-    }
+    PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel, kW, nnls_lds_bytes()));
+    if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
+    P->n_waves = occ * cus;
     P->mglob_stride = kGlobTri;
     PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * kGlobTri * sizeof(double)));
-    // the MFMA Gram step feeds the general kernel (and pnx_nnls_aty_f64); the fast kernel takes B^T y from its LDS copy of B
     if (!getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64) {  // LDS stage of Bp: n_meas * 2 KiB
         PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
         PNX_HIPN(hipFuncSetAttribute((const void *)nnls_aty_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1226,10 +1041,10 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
     // Voxels go through in chunks of kAtyChunk: the MFMA Gram step fills ATY for the chunk, the persistent
     // active-set kernel consumes it (256 voxels per resident wave at full occupancy keep the drain tail small; 2 GiB of ATY scratch).
-    const bool use_mfma = P->aty != nullptr && !P->fast;
-    const int64_t chunk = P->fast ? (n_vox > 0 ? n_vox : 1) : kAtyChunk;  // the fast kernel needs no ATY scratch: one launch
-    for (int64_t off = 0; off < n_vox; off += chunk) {
-        const int64_t c = (n_vox - off) < chunk ? (n_vox - off) : chunk;
+    if (P->qr) return nnls_qr_solve_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, stream);
+    const bool use_mfma = P->aty != nullptr;
+    for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
+        const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
         NnlsArgs a;
         a.y = y_d + (size_t)off * P->n_meas;
         a.coeff = coeff_d + (size_t)off * P->n_bins;
@@ -1261,14 +1076,8 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
             PNX_HIPN(hipGetLastError());
         }
         PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-        if (P->fast) {
-            long long grid = (c + kFastWaves - 1) / kFastWaves;
-            if (grid > P->n_blocks) grid = P->n_blocks;
-            hipLaunchKernelGGL(nnls_kernel<true>, dim3((unsigned)grid), dim3(kFastWaves * kW), nnls_fast_lds_bytes(), stream, a);
-        } else {
-            long long grid = c < P->n_waves ? c : P->n_waves;
-            hipLaunchKernelGGL(nnls_kernel<false>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
-        }
+        long long grid = c < P->n_waves ? c : P->n_waves;
+        hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
         PNX_HIPN(hipGetLastError());
     }
     return PNX_OK;

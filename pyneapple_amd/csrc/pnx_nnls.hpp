@@ -22,10 +22,9 @@ struct NnlsPlanData {
     double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
     size_t mglob_stride = 0;  // doubles per wave
     int n_waves = 0;          // persistent waves the scratch was sized for
-    int n_blocks = 0;         // persistent workgroups (fast path: 8 waves each)
-    bool fast = false;        // <= 32 measurements and a banded Toeplitz regulariser: LDS-resident basis kernel
-    double rc[5] = {0, 0, 0, 0, 0};  // reg[i][j] = rc[j - i + 2]
-    int rhb = 0;
+    double rc[5] = {0, 0, 0, 0, 0};  // banded Toeplitz regulariser (orders 1-3 of the reference): reg[i][j] = rc[j - i + 2]
+    int rhb = 0;              // its half bandwidth, 0 = general regulariser
+    bool qr = false;          // no (or an all-zero) regulariser and <= 64 measurements: QR-based kernel (pnx_nnls_qr.hip)
     unsigned long long *queue = nullptr;
 };
 
@@ -34,6 +33,8 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
 void nnls_plan_free(NnlsPlanData *P);
 int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d,
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                         int8_t *status_d, int32_t *iters_d, hipStream_t stream);
 int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream);
 int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis);
 

@@ -47,6 +47,28 @@ def test_matches_oracle_seeded(gpu, oracle, order):
     assert (((r["coefficients"] > 0) != (o["coefficients"] > 0)).sum(axis=1) == 0).mean() > 0.99
 
 
+@pytest.mark.parametrize("n_b,n_bins,d_range", [(32, 250, (0.0008, 0.5)), (16, 50, (1e-4, 0.1)), (24, 120, (0.0008, 0.5))])
+def test_unregularised_matches_oracle(gpu, oracle, n_b, n_bins, d_range):
+    """reg_order = 0, the reference's default (nnls_solver.py:37): A = B alone, rank deficient.  The QR-based kernel
+    (pnx_nnls_qr.hip) must follow the oracle's active-set path voxel by voxel -- same supports, same iteration counts."""
+    from pyneapple_amd import synth
+
+    bins = np.logspace(np.log10(d_range[0]), np.log10(d_range[1]), n_bins)
+    b = np.linspace(0.0, 1200.0, n_b)
+    basis = np.exp(-b[:, None] * bins[None, :])
+    _, y, _ = synth.make_numpy("tri_reduced", 3000, n_b, sigma=0.01, seed=5, scale=1000.0)
+    for reg in (None, np.zeros((n_bins, n_bins))):
+        r = gpu.nnls(basis, reg, y, 250)
+        o = oracle.nnls(basis, reg, y, 250, n_threads=8)
+        np.testing.assert_array_equal(r["status"], o["status"])
+        ok = o["status"] == 1
+        same = ((r["coefficients"] > 0) == (o["coefficients"] > 0)).all(axis=1)
+        assert same[ok].mean() > 0.995, f"supports differ on {(~same[ok]).sum()} voxels"
+        assert (r["iters"] == o["iters"])[ok].mean() > 0.995
+        assert _scaled_err(r["coefficients"][ok & same], o["coefficients"][ok & same]).max() < 1e-6
+        np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9)  # the minimum itself: every voxel
+
+
 def test_edge_shapes_and_failures(gpu, oracle):
     rng = np.random.default_rng(0)
     # no regulariser, more bins than measurements, > 64 bins (several bins per lane), 1 voxel, empty batch
