@@ -7,7 +7,7 @@
 // different, equally feasible column than SciPy on a few per cent of such voxels (fixture g9_nnls_250_r0).  Here the
 // passive set lives in an explicit orthonormal basis Q (n_meas x p, p <= n_meas) and a triangular R, like SciPy's own
 // QR-based kernel: entering columns are orthogonalised twice (Gram-Schmidt with re-orthogonalisation, error ~ eps *
-// cond(A)), leaving columns are removed with Givens rotations (dlartgp convention, as oracle/pnx_oracle_nnls.c).  The
+// cond(A)), leaving columns are removed with Givens rotations (LAPACK dlartgp convention: r >= 0).  The
 // problem is tiny (a 32 x p factor), so this costs a fraction of the regularised solve.
 //
 // One wavefront owns one voxel.  lane = measurement for vectors in R^m (residual, candidate column, columns of Q),
@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }  
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0) != 0; }
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Givens rotation with non-negative r (LAPACK dlartgp, as the oracle / SciPy's compiled kernel)
+// Givens rotation with non-negative r (LAPACK dlartgp, what SciPy 1.15 links)
 __device__ inline void givens(double f, double g, double &c, double &s, double &r) {
     if (g == 0) {
         c = copysign(1.0, f);
