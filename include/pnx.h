@@ -185,6 +185,40 @@ int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, 
 int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg);
 
 /*
+ * NNLS spectrum post-processing on the device: what pyneapple.utility.spectrum does per voxel
+ * (src/pyneapple/utility/spectrum.py:13-215) for all voxels at once.
+ *   find_spectrum_peaks(spectrum, bins, height, regularized): scipy.signal.find_peaks(spectrum, height=height); fractions
+ *     = peak heights, or -- regularized != 0 -- the Gaussian area height * FWHM / (2 sqrt(2 ln 2)) * sqrt(2 pi) with the FWHM
+ *     of scipy.signal.peak_widths(rel_height) (calculate_peak_area); normalised to sum 1; d = bins[peak].
+ *   apply_cutoffs(d, f, cutoffs): per range (lo, hi) no peak -> NaN, one -> kept, several -> geometric_mean_peak
+ *     (log10 of the weighted geometric mean position -- the reference's own convention -- and the summed fraction);
+ *     fractions renormalised over the ranges.
+ *   spectrum (n_vox, n_bins) host|device; bins (n_bins,) host; cutoffs (n_cut, 2) host.
+ *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks; the first max_peaks <= 16 are reported);
+ *   d_values / f_values (n_vox, max_peaks) NaN padded; d_cut / f_cut (n_vox, n_cut <= 8).  Outputs host|device as `mem`.
+ */
+int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectrum, const double *bins_host, double height,
+                                int regularized, double rel_height, int max_peaks, int32_t *n_peaks, double *d_values,
+                                double *f_values, int n_cut, const double *cutoffs_host, double *d_cut, double *f_cut, int mem,
+                                int device, void *stream);
+/*
+ * NNLS solve + spectrum post-processing in one call: the (n_vox, n_bins) spectra never leave the device (2 KB per voxel,
+ * 8.4 GB for a 256 x 256 x 64 volume); per voxel only the peak table, the cutoff table, rnorm / status / iters come back.
+ * Arguments as pnx_nnls_solve_f64 and pnx_nnls_spectrum_peaks_f64; y and every output host|device as `mem`.
+ */
+int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
+                             double height, int regularized, double rel_height, int max_peaks, int32_t *n_peaks,
+                             double *d_values, double *f_values, int n_cut, const double *cutoffs_host, double *d_cut,
+                             double *f_cut, double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
+/*
+ * float32 parameter maps (io/nifti.py:279-312 reconstruct_maps): out (n_spatial, k) zero filled, then
+ * out[linear_index[i], :] = (float) values[i, :] for the n_px fitted voxels (linear_index = C-order index into the
+ * (X, Y, Z) grid).  values (n_px, k) float64, linear_index (n_px) int64, out float32: host|device as `mem`.
+ */
+int pnx_scatter_maps_f32(const double *values, const int64_t *linear_index, int64_t n_px, int k, int64_t n_spatial, float *out,
+                         int mem, int device, void *stream);
+
+/*
  * IDEAL level plumbing on the device.
  * pnx_resize2d_f64: resize the first two axes of an (X, Y, C) array (C = product of the trailing axes, contiguous)
  *   to (TX, TY, C) with OpenCV's INTER_LINEAR (method 0) / INTER_CUBIC (method 1) arithmetic -- half-pixel centres,

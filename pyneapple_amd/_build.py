@@ -51,7 +51,7 @@ def source_ids() -> dict:
 
 def _units():
     units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_nnls_qr.o", "pnx_nnls_qr.hip", NNLS_FLAGS),
-             ("pnx_sweep.o", "pnx_sweep.hip", []),
+             ("pnx_sweep.o", "pnx_sweep.hip", []), ("pnx_spectrum.o", "pnx_spectrum.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
         units.append((f"pnx_curvefit_m{m}.o", "pnx_curvefit_inst.hip", [f"-DPNX_MODEL={m}", *CURVEFIT_FLAGS]))

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "pnx_curvefit_batch_f32", "pnx_nnls_solve_f32",
     "pnx_nnls_plan_create", "pnx_nnls_plan_destroy", "pnx_nnls_solve_f64", "pnx_nnls_aty_f64", "pnx_nnls_batch_f64",
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
-    "pnx_resize2d_f64", "pnx_ideal_bounds_f64",
+    "pnx_resize2d_f64", "pnx_ideal_bounds_f64", "pnx_nnls_spectrum_peaks_f64", "pnx_nnls_solve_peaks_f64", "pnx_scatter_maps_f32",
 ]
 
 
@@ -122,6 +122,14 @@ def load():
     lib.pnx_nnls_basis.argtypes = [C.c_int, dp, C.c_int, dp, dp, C.c_int]
     lib.pnx_nnls_regularization_matrix.restype = C.c_int
     lib.pnx_nnls_regularization_matrix.argtypes = [C.c_int, C.c_int, C.c_double, dp]
+    lib.pnx_nnls_spectrum_peaks_f64.restype = C.c_int
+    lib.pnx_nnls_spectrum_peaks_f64.argtypes = [C.c_int64, C.c_int, vp, dp, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp,
+                                                C.c_int, dp, vp, vp, C.c_int, C.c_int, vp]
+    lib.pnx_nnls_solve_peaks_f64.restype = C.c_int
+    lib.pnx_nnls_solve_peaks_f64.argtypes = [vp, C.c_int64, vp, C.c_int, dp, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp,
+                                             C.c_int, dp, vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.pnx_scatter_maps_f32.restype = C.c_int
+    lib.pnx_scatter_maps_f32.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int64, vp, C.c_int, C.c_int, vp]
     lib.pnx_sweep_f32.restype = C.c_int
     lib.pnx_sweep_f32.argtypes = [C.c_int, C.c_int64, C.c_int, fp, fp, fp, fp, fp, fp, C.c_int, vp]
     lib.pnx_sweep_f64.restype = C.c_int

@@ -148,6 +148,28 @@ class NnlsPlan:
         """Enqueue the MFMA Gram step alone: aty (n_vox, 256) = y @ basis (None: into the plan's own scratch)."""
         check(load().pnx_nnls_aty_f64(self._h, int(n_vox), ptr(y), ptr(aty), stream))
 
+    def solve_peaks(self, y, bins, max_iter=250, height=0.1, regularized=False, rel_height=0.5, max_peaks=8, cutoffs=None):
+        """Solve and reduce every spectrum to its peak table on the device (pnx_nnls_solve_peaks_f64): the (n_vox, n_bins)
+        spectra never cross PCIe.  Returns dict(n_peaks, d_values, f_values (n_vox, max_peaks) NaN padded, d_cut, f_cut
+        (n_vox, n_cut) or None, residual, status, iters)."""
+        y = np.ascontiguousarray(np.atleast_2d(y), np.float64)
+        n_vox = y.shape[0]
+        if y.shape[1] != self.n_meas:
+            raise ValueError(f"signal has {y.shape[1]} measurements, basis has {self.n_meas}")
+        bins = np.ascontiguousarray(bins, np.float64)
+        if bins.shape != (self.n_bins,):
+            raise ValueError(f"bins has shape {bins.shape}, expected ({self.n_bins},)")
+        cut = None if cutoffs is None else np.ascontiguousarray(cutoffs, np.float64).reshape(-1, 2)
+        n_cut = 0 if cut is None else cut.shape[0]
+        out = dict(n_peaks=np.empty(n_vox, np.int32), d_values=np.empty((n_vox, max_peaks)), f_values=np.empty((n_vox, max_peaks)),
+                   d_cut=np.empty((n_vox, n_cut)) if n_cut else None, f_cut=np.empty((n_vox, n_cut)) if n_cut else None,
+                   residual=np.empty(n_vox), status=np.empty(n_vox, np.int8), iters=np.empty(n_vox, np.int32))
+        check(load().pnx_nnls_solve_peaks_f64(self._h, n_vox, ptr(y), int(max_iter), ptr(bins), float(height), int(bool(regularized)),
+                                              float(rel_height), int(max_peaks), ptr(out["n_peaks"]), ptr(out["d_values"]),
+                                              ptr(out["f_values"]), n_cut, ptr(cut), ptr(out["d_cut"]), ptr(out["f_cut"]),
+                                              ptr(out["residual"]), ptr(out["status"]), ptr(out["iters"]), MEM_HOST, None))
+        return out
+
     def close(self):
         if self._h:
             load().pnx_nnls_plan_destroy(self._h)
@@ -186,6 +208,54 @@ def nnls_basis(b, bins, device=0):
     bins = np.ascontiguousarray(bins, np.float64)
     out = np.empty((b.size, bins.size))
     check(load().pnx_nnls_basis(b.size, ptr(b), bins.size, ptr(bins), ptr(out), device))
+    return out
+
+
+def spectrum_peaks(spectrum, bins, height=0.1, regularized=False, rel_height=0.5, max_peaks=8, cutoffs=None, device=0):
+    """find_spectrum_peaks (+ apply_cutoffs) of utility/spectrum.py for every row of `spectrum` (n_vox, n_bins) at once, on
+    the device.  numpy arrays in and out, or torch-cuda tensors for `spectrum` (then the outputs are torch tensors)."""
+    _lib.require_device()
+    tensor = _is_torch(spectrum)
+    if not tensor:
+        spectrum = np.ascontiguousarray(np.atleast_2d(spectrum), np.float64)
+    n_vox, n_bins = spectrum.shape
+    bins = np.ascontiguousarray(bins, np.float64)
+    if bins.shape != (n_bins,):
+        raise ValueError(f"bins has shape {bins.shape}, expected ({n_bins},)")
+    cut = None if cutoffs is None else np.ascontiguousarray(cutoffs, np.float64).reshape(-1, 2)
+    n_cut = 0 if cut is None else cut.shape[0]
+    if tensor:
+        import torch
+
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=spectrum.device)
+        out = dict(n_peaks=mk(n_vox, torch.int32), d_values=mk((n_vox, max_peaks), torch.float64),
+                   f_values=mk((n_vox, max_peaks), torch.float64),
+                   d_cut=mk((n_vox, n_cut), torch.float64) if n_cut else None, f_cut=mk((n_vox, n_cut), torch.float64) if n_cut else None)
+        device = spectrum.device.index
+        stream = torch.cuda.current_stream(spectrum.device).cuda_stream
+    else:
+        out = dict(n_peaks=np.empty(n_vox, np.int32), d_values=np.empty((n_vox, max_peaks)), f_values=np.empty((n_vox, max_peaks)),
+                   d_cut=np.empty((n_vox, n_cut)) if n_cut else None, f_cut=np.empty((n_vox, n_cut)) if n_cut else None)
+        stream = None
+    check(load().pnx_nnls_spectrum_peaks_f64(n_vox, n_bins, ptr(spectrum), ptr(bins), float(height), int(bool(regularized)),
+                                             float(rel_height), int(max_peaks), ptr(out["n_peaks"]), ptr(out["d_values"]),
+                                             ptr(out["f_values"]), n_cut, ptr(cut), ptr(out["d_cut"]), ptr(out["f_cut"]),
+                                             MEM_DEVICE if tensor else MEM_HOST, int(device), stream))
+    return out
+
+
+def scatter_maps(values, pixel_indices, spatial_shape, device=0):
+    """float32 volume `spatial_shape (+ values.shape[1:])`, zero outside the fitted voxels, values[i] at pixel_indices[i]
+    (io/nifti.py:279-312 reconstruct_maps) -- laid out on the device (pnx_scatter_maps_f32)."""
+    _lib.require_device()
+    values = np.ascontiguousarray(values, np.float64)
+    idx = np.asarray(pixel_indices)
+    spatial_shape = tuple(int(s) for s in spatial_shape)
+    lin = np.ascontiguousarray(np.ravel_multi_index(tuple(idx.T), spatial_shape), np.int64)
+    n_px = values.shape[0]
+    k = int(np.prod(values.shape[1:], dtype=np.int64)) if values.ndim > 1 else 1
+    out = np.empty(spatial_shape + values.shape[1:], np.float32)
+    check(load().pnx_scatter_maps_f32(ptr(values), ptr(lin), n_px, k, int(np.prod(spatial_shape)), ptr(out), MEM_HOST, int(device), None))
     return out
 
 

@@ -791,6 +791,84 @@ int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int m
     return nnls_solve<float>(plan, n_vox, y, max_iter, coeff, rnorm, status, iters, mem, stream);
 }
 
+int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
+                             double height, int regularized, double rel_height, int max_peaks, int32_t *n_peaks,
+                             double *d_values, double *f_values, int n_cut, const double *cutoffs_host, double *d_cut,
+                             double *f_cut, double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream) {
+    if (!plan) return set_error(PNX_ERR_INVALID, "plan is NULL");
+    if (n_vox < 0 || (n_vox && (!y || !rnorm))) return set_error(PNX_ERR_INVALID, "NULL data pointer");
+    if (mem != PNX_MEM_HOST && mem != PNX_MEM_DEVICE) return set_error(PNX_ERR_INVALID, "mem=%d", mem);
+    if (n_vox == 0) return PNX_OK;
+    NnlsPlanData &P = plan->d;
+    PNX_HIP(hipSetDevice(P.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (max_iter <= 0) max_iter = 3 * P.n_bins;
+    std::lock_guard<std::mutex> plan_lock(plan->mu);
+    // spectra of one chunk live in device scratch only: solve -> peak analysis -> next chunk
+    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 18, 1024, 1 << 22);
+    const size_t nv = (size_t)n_vox, cap = nv < chunk ? nv : chunk;
+    DevBuf spec, stage;
+    int rc;
+    if ((rc = spec.alloc(cap * P.n_bins * sizeof(double)))) return rc;
+    const bool host = mem == PNX_MEM_HOST;
+    Carver c;
+    double *sy = nullptr, *sr = nullptr, *sd = nullptr, *sf = nullptr, *sdc = nullptr, *sfc = nullptr;
+    int8_t *ss = nullptr;
+    int32_t *si = nullptr, *sn = nullptr;
+    if (host) {
+        for (int pass = 0; pass < 2; ++pass) {
+            c = Carver();
+            c.base = (char *)stage.p;
+            sy = (double *)c.take(cap * P.n_meas * 8);
+            sr = (double *)c.take(cap * 8);
+            sd = (double *)c.take(cap * (max_peaks > 0 ? max_peaks : 1) * 8);
+            sf = (double *)c.take(cap * (max_peaks > 0 ? max_peaks : 1) * 8);
+            sdc = (double *)c.take(cap * (n_cut > 0 ? n_cut : 1) * 8);
+            sfc = (double *)c.take(cap * (n_cut > 0 ? n_cut : 1) * 8);
+            si = (int32_t *)c.take(cap * 4);
+            sn = (int32_t *)c.take(cap * 4);
+            ss = (int8_t *)c.take(cap);
+            if (pass == 0 && (rc = stage.alloc(c.off))) return rc;
+        }
+    }
+    for (size_t off = 0; off < nv; off += chunk) {
+        const size_t n = (nv - off) < chunk ? (nv - off) : chunk;
+        const double *yd = y + off * P.n_meas;
+        if (host) {
+            PNX_HIP(hipMemcpyAsync(sy, yd, n * P.n_meas * 8, hipMemcpyHostToDevice, st));
+            yd = sy;
+        }
+        double *rd = host ? sr : rnorm + off;
+        int8_t *std_ = host ? ss : (status ? status + off : nullptr);
+        int32_t *itd = host ? si : (iters ? iters + off : nullptr);
+        if ((rc = nnls_solve_device(&P, (int64_t)n, yd, max_iter, (double *)spec.p, rd, std_, itd, st))) return rc;
+        rc = pnx_nnls_spectrum_peaks_f64((int64_t)n, P.n_bins, (const double *)spec.p, bins_host, height, regularized, rel_height,
+                                         max_peaks, host ? sn : (n_peaks ? n_peaks + off : nullptr),
+                                         host ? sd : (d_values ? d_values + off * max_peaks : nullptr),
+                                         host ? sf : (f_values ? f_values + off * max_peaks : nullptr), n_cut, cutoffs_host,
+                                         host ? sdc : (d_cut ? d_cut + off * n_cut : nullptr),
+                                         host ? sfc : (f_cut ? f_cut + off * n_cut : nullptr), PNX_MEM_DEVICE, P.device, st);
+        if (rc) return rc;
+        if (host) {
+            PNX_HIP(hipMemcpyAsync(rnorm + off, sr, n * 8, hipMemcpyDeviceToHost, st));
+            if (status) PNX_HIP(hipMemcpyAsync(status + off, ss, n, hipMemcpyDeviceToHost, st));
+            if (iters) PNX_HIP(hipMemcpyAsync(iters + off, si, n * 4, hipMemcpyDeviceToHost, st));
+            if (n_peaks) PNX_HIP(hipMemcpyAsync(n_peaks + off, sn, n * 4, hipMemcpyDeviceToHost, st));
+            if (max_peaks > 0) {
+                PNX_HIP(hipMemcpyAsync(d_values + off * max_peaks, sd, n * max_peaks * 8, hipMemcpyDeviceToHost, st));
+                PNX_HIP(hipMemcpyAsync(f_values + off * max_peaks, sf, n * max_peaks * 8, hipMemcpyDeviceToHost, st));
+            }
+            if (n_cut > 0) {
+                PNX_HIP(hipMemcpyAsync(d_cut + off * n_cut, sdc, n * n_cut * 8, hipMemcpyDeviceToHost, st));
+                PNX_HIP(hipMemcpyAsync(f_cut + off * n_cut, sfc, n * n_cut * 8, hipMemcpyDeviceToHost, st));
+            }
+        }
+        // the spectrum scratch is reused by the next chunk: in-order on one stream
+    }
+    PNX_HIP(hipStreamSynchronize(st));  // the scratch buffers are freed on return
+    return PNX_OK;
+}
+
 int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream) {
     if (!plan) return set_error(PNX_ERR_INVALID, "plan is NULL");
     if (n_vox < 0 || (n_vox && !y_dev)) return set_error(PNX_ERR_INVALID, "NULL data pointer");

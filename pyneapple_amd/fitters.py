@@ -216,8 +216,18 @@ class HipFitterBase(_FitterBase):
         vol[tuple(idx.T)] = flat_values
         return vol
 
-    def parameter_maps(self, dtype=np.float32) -> dict:
-        """{name: (X, Y, Z[, n_bins]) volume}, zeros outside the mask (io/nifti.py:279-312 reconstruct_maps)."""
+    def parameter_maps(self, dtype=np.float32, on_device: bool = False) -> dict:
+        """{name: (X, Y, Z[, n_bins]) volume}, zeros outside the mask (io/nifti.py:279-312 reconstruct_maps).
+        on_device: narrow to float32 and lay the volumes out on the GPU (pnx_scatter_maps_f32) -- half the bytes of the
+        float64 values go back over PCIe, and no host-side zero fill + fancy-index scatter."""
+        if on_device:
+            from . import api
+
+            if np.dtype(dtype) != np.float32:
+                raise ValueError("on_device parameter maps are float32 (the NIfTI writer's type, io/nifti.py:306)")
+            dev = getattr(self.solver, "device", 0)
+            return {name: api.scatter_maps(np.asarray(v), self.pixel_indices, self.image_shape[:-1], dev)
+                    for name, v in self.fitted_params_.items()}
         idx = tuple(np.asarray(self.pixel_indices).T)
         spatial = self.image_shape[:-1]
         out = {}

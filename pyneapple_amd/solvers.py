@@ -336,6 +336,36 @@ class HipNNLSSolver(NNLSBase):
         """Kept for interface parity (nnls_solver.py:75-86); the HIP path never materialises it."""
         return np.concatenate((signal, np.zeros((signal.shape[0], self.model.n_bins))), axis=1)
 
+    def fit_peaks(self, xdata: np.ndarray, signal: np.ndarray, height: float = 0.1, cutoffs=None, max_peaks: int = 8,
+                  regularized: bool | None = None) -> "HipNNLSSolver":
+        """Fit and reduce every spectrum to its peak table on the device (pnx_nnls_solve_peaks_f64): what a caller of the
+        reference does with `fit` followed by a Python loop over `find_spectrum_peaks` / `apply_cutoffs`
+        (utility/spectrum.py:51-215), without the (n_pixels, n_bins) coefficient array -- 8.4 GB for a 256 x 256 x 64
+        volume -- crossing PCIe.  `regularized` defaults to reg_order != 0 (spectrum.py:68-71).
+        params_: "d_values", "f_values" (n_pixels, max_peaks) NaN padded, "n_peaks", and with `cutoffs` "d_cut", "f_cut"."""
+        self._reset_state()
+        xdata = np.asarray(xdata, float)
+        signal = np.asarray(signal, float)
+        basis = np.asarray(self.model.get_basis(xdata), float)
+        if signal.ndim == 1:
+            signal = signal[np.newaxis, :]
+        if signal.ndim != 2 or signal.shape[1] != basis.shape[0]:
+            raise ValueError(f"signal shape {signal.shape} does not match the basis ({basis.shape[0]} measurements)")
+        self.n_pixels = signal.shape[0]
+        plan = api.NnlsPlan(basis, self.get_regularization_matrix(), self.device)
+        try:
+            res = plan.solve_peaks(np.ascontiguousarray(signal), np.asarray(self.model.bins, float),
+                                   int(self.max_iter) if self.max_iter else 0, height=height,
+                                   regularized=bool(self.reg_order) if regularized is None else regularized,
+                                   max_peaks=max_peaks, cutoffs=cutoffs)
+        finally:
+            plan.close()
+        for key in ("d_values", "f_values", "n_peaks", "d_cut", "f_cut"):
+            if res[key] is not None:
+                self.params_[key] = res[key]
+        self.diagnostics_.update(residual=res["residual"], status=res["status"], iters=res["iters"])
+        return self
+
     def fit(self, xdata: np.ndarray, signal: np.ndarray, pixel_fixed_params=None, **kwargs) -> "HipNNLSSolver":
         self._reset_state()
         xdata = np.asarray(xdata, float)
