@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <vector>
 
 #include "pnx_internal.hpp"
 
@@ -18,55 +17,57 @@ struct Taps {  // per output coordinate: 4 source indices and weights (linear: 2
     double w[4];
 };
 
-static void make_taps(int n_src, int n_dst, int method, std::vector<Taps> &t) {
-    t.resize(n_dst);
+// The taps of output coordinate d, computed where they are used: a handful of flops per output element of an HBM-bound
+// kernel -- and no tap table to build on the host, upload and wait for (a device-mode call only enqueues, and can be
+// captured into a HIP graph).
+__host__ __device__ inline Taps make_taps(int n_src, int n_dst, int method, int d) {
+#pragma clang fp contract(off)  // the same roundings as a host evaluation: floor(f) must not depend on an FMA
     const double scale = (double)n_src / n_dst;
-    for (int d = 0; d < n_dst; ++d) {
-        const double f = (d + 0.5) * scale - 0.5;
-        int s = (int)std::floor(f);
-        double fr = f - s;
-        Taps &T = t[d];
-        for (int k = 0; k < 4; ++k) {
-            T.idx[k] = 0;
-            T.w[k] = 0;
+    const double f = (d + 0.5) * scale - 0.5;
+    int s = (int)floor(f);
+    double fr = f - s;
+    Taps T;
+    for (int k = 0; k < 4; ++k) {
+        T.idx[k] = 0;
+        T.w[k] = 0;
+    }
+    if (method == 0) {  // INTER_LINEAR
+        if (s < 0) {
+            s = 0;
+            fr = 0;
         }
-        if (method == 0) {  // INTER_LINEAR
-            if (s < 0) {
-                s = 0;
-                fr = 0;
-            }
-            if (s >= n_src - 1) {
-                s = n_src - 1;
-                fr = 0;
-            }
-            T.idx[0] = s;
-            T.w[0] = 1.0 - fr;
-            T.idx[1] = s + 1 < n_src ? s + 1 : n_src - 1;
-            T.w[1] = fr;
-        } else {  // INTER_CUBIC, A = -0.75
-            const double A = -0.75, x = fr;
-            const double c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
-            const double c1 = ((A + 2) * x - (A + 3)) * x * x + 1;
-            const double c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
-            const double c[4] = {c0, c1, c2, 1.0 - c0 - c1 - c2};
-            for (int k = 0; k < 4; ++k) {
-                int i = s - 1 + k;
-                i = i < 0 ? 0 : (i >= n_src ? n_src - 1 : i);
-                T.idx[k] = i;
-                T.w[k] = c[k];
-            }
+        if (s >= n_src - 1) {
+            s = n_src - 1;
+            fr = 0;
+        }
+        T.idx[0] = s;
+        T.w[0] = 1.0 - fr;
+        T.idx[1] = s + 1 < n_src ? s + 1 : n_src - 1;
+        T.w[1] = fr;
+    } else {  // INTER_CUBIC, A = -0.75
+        const double A = -0.75, x = fr;
+        const double c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        const double c1 = ((A + 2) * x - (A + 3)) * x * x + 1;
+        const double c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        const double c[4] = {c0, c1, c2, 1.0 - c0 - c1 - c2};
+        for (int k = 0; k < 4; ++k) {
+            int i = s - 1 + k;
+            i = i < 0 ? 0 : (i >= n_src ? n_src - 1 : i);
+            T.idx[k] = i;
+            T.w[k] = c[k];
         }
     }
+    return T;
 }
 
-__global__ void resize2d_kernel(const double *__restrict__ in, double *__restrict__ out, const Taps *__restrict__ tx,
-                                const Taps *__restrict__ ty, int Y, long long C, int TX, int TY) {
+__global__ void resize2d_kernel(const double *__restrict__ in, double *__restrict__ out, int X, int Y, long long C, int TX,
+                                int TY, int method) {
     const long long total = (long long)TX * TY * C;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long c = e % C;
         const long long xy = e / C;
         const int oy = (int)(xy % TY), ox = (int)(xy / TY);
-        const Taps a = tx[ox], b = ty[oy];
+        const Taps a = make_taps(X, TX, method, ox), b = make_taps(Y, TY, method, oy);
         // rows first, then columns -- the order of the numpy restatement (ideal.py resize2d: Wx, then Wy)
         double acc = 0;
 #pragma unroll
@@ -80,17 +81,20 @@ __global__ void resize2d_kernel(const double *__restrict__ in, double *__restric
     }
 }
 
+struct BoundsArgs {  // by value: nothing to upload, nothing to wait for
+    double lo[PNX_MAX_PARAMS], hi[PNX_MAX_PARAMS], tol[PNX_MAX_PARAMS];
+};
+
 // p0 = clip(map, lo, hi); lower = clip(p0 (1 - tol), lo, hi); upper = clip(p0 (1 + tol), lo, hi), written
 // parameter-major (n_params, n_px) -- the layout the solver takes (ideal.py:182-189, validation.py:177-203).
 // `map` is (n_px, n_params) (a parameter map with the parameter axis last).
-__global__ void ideal_bounds_kernel(const double *__restrict__ map, long long n_px, int n_params, const double *__restrict__ lo,
-                                    const double *__restrict__ hi, const double *__restrict__ tol, double *__restrict__ p0,
-                                    double *__restrict__ lower, double *__restrict__ upper) {
+__global__ void ideal_bounds_kernel(const double *__restrict__ map, long long n_px, int n_params, const BoundsArgs B,
+                                    double *__restrict__ p0, double *__restrict__ lower, double *__restrict__ upper) {
     const long long total = n_px * n_params;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(e / n_px);
         const long long v = e - (long long)k * n_px;
-        const double l = lo[k], h = hi[k], t = tol[k];
+        const double l = B.lo[k], h = B.hi[k], t = B.tol[k];
         double p = map[v * n_params + k];
         p = fmin(fmax(p, l), h);
         p0[e] = p;
@@ -122,39 +126,31 @@ int pnx_resize2d_f64(const double *in, int X, int Y, int64_t C, double *out, int
     if (device < 0 || device >= ndev) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
     RS_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
-    std::vector<Taps> tx, ty;
-    make_taps(X, TX, method, tx);
-    make_taps(Y, TY, method, ty);
-    Taps *dtx = nullptr, *dty = nullptr;
-    RS_HIP(hipMallocAsync((void **)&dtx, sizeof(Taps) * TX, st));
-    RS_HIP(hipMallocAsync((void **)&dty, sizeof(Taps) * TY, st));
-    RS_HIP(hipMemcpyAsync(dtx, tx.data(), sizeof(Taps) * TX, hipMemcpyHostToDevice, st));
-    RS_HIP(hipMemcpyAsync(dty, ty.data(), sizeof(Taps) * TY, hipMemcpyHostToDevice, st));
-    RS_HIP(hipStreamSynchronize(st));  // the tap tables live in pageable host vectors that die with this call
     const size_t n_in = (size_t)X * Y * C, n_out = (size_t)TX * TY * C;
     const double *din = in;
     double *dout = out;
-    double *tmp_in = nullptr, *tmp_out = nullptr;
+    struct Tmp {  // freed on every return path
+        void *p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } tmp_in, tmp_out;
     if (mem == PNX_MEM_HOST) {
-        RS_HIP(hipMalloc((void **)&tmp_in, n_in * sizeof(double)));
-        RS_HIP(hipMalloc((void **)&tmp_out, n_out * sizeof(double)));
-        RS_HIP(hipMemcpyAsync(tmp_in, in, n_in * sizeof(double), hipMemcpyHostToDevice, st));
-        din = tmp_in;
-        dout = tmp_out;
+        RS_HIP(hipMalloc(&tmp_in.p, n_in * sizeof(double)));
+        RS_HIP(hipMalloc(&tmp_out.p, n_out * sizeof(double)));
+        RS_HIP(hipMemcpyAsync(tmp_in.p, in, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+        din = (const double *)tmp_in.p;
+        dout = (double *)tmp_out.p;
     }
     size_t blocks = (n_out + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(resize2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, din, dout, dtx, dty, Y, (long long)C, TX, TY);
+    hipLaunchKernelGGL(resize2d_kernel, dim3((unsigned)blocks), dim3(256), 0, st, din, dout, X, Y, (long long)C, TX, TY, method);
     RS_HIP(hipGetLastError());
-    RS_HIP(hipFreeAsync(dtx, st));
-    RS_HIP(hipFreeAsync(dty, st));
     if (mem == PNX_MEM_HOST) {
-        RS_HIP(hipMemcpyAsync(out, tmp_out, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+        RS_HIP(hipMemcpyAsync(out, dout, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
         RS_HIP(hipStreamSynchronize(st));
-        (void)hipFree(tmp_in);
-        (void)hipFree(tmp_out);
     }
-    return PNX_OK;
+    return PNX_OK;  // PNX_MEM_DEVICE: enqueued only
 }
 
 int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const double *lo_host, const double *hi_host,
@@ -164,22 +160,17 @@ int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const do
     if (n_px == 0) return PNX_OK;
     RS_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
-    double *d = nullptr;
-    RS_HIP(hipMallocAsync((void **)&d, sizeof(double) * 3 * PNX_MAX_PARAMS, st));
-    double h[3 * PNX_MAX_PARAMS] = {0};
-    for (int k = 0; k < n_params; ++k) {
-        h[k] = lo_host[k];
-        h[PNX_MAX_PARAMS + k] = hi_host[k];
-        h[2 * PNX_MAX_PARAMS + k] = tol_host[k];
+    BoundsArgs B;
+    for (int k = 0; k < PNX_MAX_PARAMS; ++k) {
+        B.lo[k] = k < n_params ? lo_host[k] : 0.0;
+        B.hi[k] = k < n_params ? hi_host[k] : 0.0;
+        B.tol[k] = k < n_params ? tol_host[k] : 0.0;
     }
-    RS_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st));
-    RS_HIP(hipStreamSynchronize(st));  // h is on this stack frame
     size_t blocks = ((size_t)n_px * n_params + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(ideal_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map, (long long)n_px, n_params, d,
-                       d + PNX_MAX_PARAMS, d + 2 * PNX_MAX_PARAMS, p0, lower, upper);
+    hipLaunchKernelGGL(ideal_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map, (long long)n_px, n_params, B, p0,
+                       lower, upper);
     RS_HIP(hipGetLastError());
-    RS_HIP(hipFreeAsync(d, st));
     return PNX_OK;
 }
 }
