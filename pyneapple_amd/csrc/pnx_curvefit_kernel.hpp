@@ -216,6 +216,38 @@ __device__ inline double fast_sqrt_rsqrt(double x, double *rs) {
     return g;
 }
 
+// exp(x), fp64, <= 1 ulp class: the reduction and the degree-11 polynomial of the device library's exp (k = rint(x / ln 2),
+// r = x - k ln2_hi - k ln2_lo, |r| <= 0.347) without its overflow / underflow selects -- v_ldexp_f64 saturates to inf / 0
+// by itself, v_cvt_i32_f64 saturates k, NaN propagates through the polynomial -- and with the polynomial split into
+// even / odd halves (two dependent chains of 6 instead of one of 11: the row pass evaluates 3 of these per row at one
+// wave per SIMD, where the FMA latency of a single chain is exposed).
+#ifndef PNX_CF_FAST_EXP
+#define PNX_CF_FAST_EXP 1
+#endif
+__device__ inline double exp_fast(double x) {
+#if PNX_CF_FAST_EXP
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(k, -0.6931471805599453, x);
+    r = fma(k, -2.3190468138462996e-17, r);
+    const double r2 = r * r;
+    // exp(r) = 1 + r (1 + r q(r)), q = c2 + c3 r + ... + c11 r^9 with the library's minimax coefficients
+    double qe = 2.7630903490112654e-07;         // c10
+    qe = fma(qe, r2, 2.480149103909504e-05);    // c8
+    qe = fma(qe, r2, 0.0013888888945916382);    // c6
+    qe = fma(qe, r2, 0.041666666666519754);     // c4
+    qe = fma(qe, r2, 0.5000000000000012);       // c2
+    double qo = 2.502232256764614e-08;          // c11
+    qo = fma(qo, r2, 2.755751454582531e-06);    // c9
+    qo = fma(qo, r2, 0.00019841269589115522);   // c7
+    qo = fma(qo, r2, 0.008333333333455043);     // c5
+    qo = fma(qo, r2, 0.16666666666666477);      // c3
+    const double q = fma(r, qo, qe);
+    return ldexp(fma(r, fma(r, q, 1.0), 1.0), __double2int_rz(k));  // v_cvt_i32_f64 saturates, v_ldexp_f64 over / underflows by itself
+#else
+    return exp(x);
+#endif
+}
+
 // Merge RB rows (J part in blk[r][0..N), rhs in blk[r][N]) into the upper-triangular factor R | q
 // by Householder reflections acting on [R[k][k]; blk[:,k]].  Afterwards blk is garbage.
 template <int N, int RB> __device__ inline void qr_merge(double (&R)[N][N], double (&q)[N], double (&blk)[RB][N + 1]) {
@@ -789,7 +821,7 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
                     yfinite = yfinite && isfinite(yi);
                     double E[NC];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) E[c] = exp(nb * pe[M::dpos(c)]);
+                    for (int c = 0; c < NC; ++c) E[c] = exp_fast(nb * pe[M::dpos(c)]);
                     const double base = M::signal(pe, E);
                     const double r0 = (T1 ? base * A1 * eTM : base) - yi;
                     double jr[N];
@@ -809,6 +841,11 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
                                 if (comp_of_param<MODEL>(k) >= 0) {
                                     const double z = nb * dxv[k];
                                     double gz;
+#if PNX_CF_FAST_EXP
+                                    if (fabs(z) < 2e-4)  // dx ~ 1.5e-8 max(1, |D|): the normal case; z^4 / 120 < 2e-17
+                                        gz = fma(z, fma(z, fma(z, 1.0 / 24, 1.0 / 6), 0.5), 1.0);
+                                    else
+#endif
                                     if (fabs(z) < 1e-3)
                                         gz = 1.0 + z * (0.5 + z * (1.0 / 6 + z * (1.0 / 24 + z * (1.0 / 120 + z * (1.0 / 720)))));
                                     else

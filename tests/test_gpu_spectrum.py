@@ -86,7 +86,9 @@ def test_fit_peaks_keeps_the_spectra_on_the_device(gpu):
     np.testing.assert_array_equal(f.diagnostics_["status"], a.diagnostics_["status"])
     # three compartments recovered as three ranges on (almost) every voxel
     assert (np.isfinite(f.params_["d_cut"]).sum(axis=1) == 3).mean() > 0.5
-    np.testing.assert_allclose(np.nansum(f.params_["f_cut"], axis=1), 1.0, rtol=1e-12)
+    has = np.isfinite(f.params_["f_cut"]).any(axis=1)  # a voxel without a peak inside any range stays all-NaN
+    assert has.mean() > 0.99
+    np.testing.assert_allclose(np.nansum(f.params_["f_cut"], axis=1)[has], 1.0, rtol=1e-12)
 
 
 def test_parameter_maps_on_device(gpu):
