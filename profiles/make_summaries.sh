@@ -43,9 +43,19 @@ for name, fn, nvox in (("curvefit_kernel<4, 5, true, false, false>", f"profiles/
                  "salu_instructions_per_voxel": d.get("SQ_INSTS_SALU", 0) / nvox,
                  "valu_issue_busy": d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], "source": fn,
                  "note": "64 lanes counted for every issued fp64 VALU instruction (FMA = 2 flop); multiply by lane_utilisation for flops on active lanes"}
+import os, sys
+sys.path.insert(0, os.getcwd())
+from pyneapple_amd import _build
+ids = _build.source_ids()  # bench.py replays these counters only while the kernel sources still hash to this
+out["_source_ids"] = ids
 json.dump(out, open(f"profiles/{tag}_flops.json", "w"), indent=1)
+t = json.load(open(f"profiles/{tag}_traffic.json"))
+t["_source_ids"] = ids
+t["_nnls_launch_voxels"] = 1 << 20
+json.dump(t, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 for k, v in out.items():
-    print(k[:30], {a: round(b, 3) for a, b in v.items() if isinstance(b, float)})
+    if isinstance(v, dict) and not k.startswith("_"):
+        print(k[:30], {a: round(b, 3) for a, b in v.items() if isinstance(b, float)})
 b = json.load(open(f"profiles/{tag}_bench.json"))
 print("bench:", b["value"], b["secondary"]["value"], b["roofline_sweep"]["frac"], b["roofline_mfma"]["frac"])
 PY

@@ -1063,8 +1063,8 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
                         nn += W[i][k] * W[i][k];
                         dq += Vw[i][k] * q2[i];
                     }
-                    nn = sqrt(nn);
-                    const double inv = nn > 0 ? 1.0 / nn : 0.0;
+                    double inv = 0.0;  // singular value and its reciprocal from one v_rsq_f64 seed (normalisation only: ~1 ulp is fine)
+                    if (nn > 0) nn = fast_sqrt_rsqrt(nn, &inv);
                     s[k] = nn;
                     uf[k] = dq;
 #pragma unroll
