@@ -501,7 +501,7 @@ def main(argv=None):
                             "frac": ach2 / HBM_PEAK_GBS,
                             "traffic": nnls_traffic(leg2.n_vox) if (not args.voxels and world == 1) else None,
                             "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel, "kernel_ms_avg": k2avg * 1e3,
-                            "note": "the active-set loop is VALU-issue bound (DESIGN.md 4.3)"}}
+                            "note": "bounded by voxels in flight per CU (16: LDS and VGPRs) x per-iteration latency, not by HBM (profiles/r02_nnls_experiments.md)"}}
         fl2 = pmc_flops("nnls_kernel", "nnls")
         if fl2:
             tf2 = fl2["fp64_flop_per_voxel_issued"] * leg2.n_vox / k2avg / 1e12

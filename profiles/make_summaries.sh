@@ -6,7 +6,7 @@ src=$1; tag=$2
 python3 - "$src" "$tag" <<'PY'
 import csv, glob, sys
 src, tag = sys.argv[1], sys.argv[2]
-f = glob.glob(f"{src}/kt/*/*_kernel_stats.csv")[0]
+f = glob.glob(f"{src}/kt/**/*_kernel_stats.csv", recursive=True)[0]
 rows = list(csv.reader(open(f)))
 with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as o:
     w = csv.writer(o); w.writerow(rows[0])
