@@ -230,10 +230,25 @@ class NnlsLeg:
         dt = float(np.mean(ts))
         d2h = sum(a.nbytes for a in r.values())
         same = bool((self.torch.from_numpy(r["coefficients"][:65536]).to(self.coeff.device) == self.coeff[:65536]).all().item())
-        return {"workload": f"{n} voxels of the same volume, host (numpy) arrays in and out through PNX_MEM_HOST",
-                "value": n / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes),
-                "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps,
-                "equals_device_resident_result": same}
+        out = {"workload": f"{n} voxels of the same volume, host (numpy) arrays in and out through PNX_MEM_HOST",
+               "value": n / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes),
+               "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps,
+               "equals_device_resident_result": same}
+        del r
+        # the same fit with the spectrum post-processing on the device (pnx_nnls_solve_peaks_f64: find_spectrum_peaks +
+        # apply_cutoffs of utility/spectrum.py per voxel): a peak table comes back instead of 2 KB per voxel
+        cuts = [(0.0008, 0.003), (0.003, 0.02), (0.02, 0.5)]
+        kw = dict(max_iter=self.cfg["max_iter"], height=0.1, regularized=True, max_peaks=8, cutoffs=cuts)
+        rp = self.plan.solve_peaks(y[: min(n, 1 << 16)], self.bins, **kw)
+        del rp
+        t = time.perf_counter()
+        rp = self.plan.solve_peaks(y, self.bins, **kw)
+        dtp = time.perf_counter() - t
+        out["with_peak_tables_instead_of_spectra"] = {
+            "value": n / dtp, "unit": "voxels/s", "ms_per_step": dtp * 1e3,
+            "d2h_bytes": int(sum(a.nbytes for a in rp.values() if a is not None)),
+            "mean_peaks_per_voxel": float(rp["n_peaks"].mean())}
+        return out
 
     def cpu_baseline(self):
         from oracle import pnx_oracle as O

@@ -235,6 +235,23 @@ int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const do
                          const double *tol_host, double *p0, double *lower, double *upper, int device, void *stream);
 
 /*
+ * IDEAL level plumbing between the resize and the fit (fitters/ideal.py:199-254), device pointers:
+ * pnx_mask_select_f64: C-order indices of mask[i] > threshold (ideal.py:199 thresholds the resized segmentation) into idx,
+ *   their number into *n_selected (host) -- synchronises the stream, the caller sizes the level's arrays with it;
+ * pnx_gather_rows_f64: dst (n_sel, c) = src[idx, :] (signal rows / start values of the fitted voxels, ideal.py:211-216);
+ * pnx_scatter_rows_t_f64: the level's parameter map (n_total, k), zero outside the fitted voxels, from the solver's
+ *   parameter-major estimates popt (k, n_sel) (ideal.py:243-252); idx NULL = every voxel in order;
+ * pnx_row_ss_tot_f64: sum_j (y_ij - mean_i)^2 per row, the SS_tot of R^2 (fitters/base.py:179-183).
+ * The last three only enqueue.
+ */
+int pnx_mask_select_f64(const double *mask, int64_t n, double threshold, int64_t *idx, int64_t *n_selected, int device,
+                        void *stream);
+int pnx_gather_rows_f64(const double *src, int64_t c, const int64_t *idx, int64_t n_sel, double *dst, int device, void *stream);
+int pnx_scatter_rows_t_f64(const double *popt, const int64_t *idx, int64_t n_sel, int k, int64_t n_total, double *pmap, int device,
+                           void *stream);
+int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int device, void *stream);
+
+/*
  * Residual / Jacobian / normal-equation sweep at given parameters (one pass of the LM inner loop as a
  * standalone, HBM-streaming kernel): for every voxel reads y (n_b) and params (n_all), writes
  * cost = 0.5*||r||^2, g = J^T r (n_all) and the upper triangle of J^T J (n_all(n_all+1)/2).

@@ -287,6 +287,25 @@ def ideal_bounds_device(param_map, n_px, lo, hi, tol, p0, lower, upper, device, 
                                       ptr(upper), int(device), stream))
 
 
+def mask_select_device(mask, threshold, idx, device, stream=None) -> int:
+    """idx[:k] = C-order indices of mask > threshold (float64 tensor, any shape); returns k (synchronises the stream)."""
+    k = C.c_int64(0)
+    check(load().pnx_mask_select_f64(ptr(mask), int(mask.numel()), float(threshold), ptr(idx), C.byref(k), int(device), stream))
+    return int(k.value)
+
+
+def gather_rows_device(src, c, idx, n_sel, dst, device, stream=None):
+    check(load().pnx_gather_rows_f64(ptr(src), int(c), ptr(idx), int(n_sel), ptr(dst), int(device), stream))
+
+
+def scatter_rows_t_device(popt, idx, n_sel, k, n_total, pmap, device, stream=None):
+    check(load().pnx_scatter_rows_t_f64(ptr(popt), ptr(idx), int(n_sel), int(k), int(n_total), ptr(pmap), int(device), stream))
+
+
+def row_ss_tot_device(y, n, c, out, device, stream=None):
+    check(load().pnx_row_ss_tot_f64(ptr(y), int(n), int(c), ptr(out), int(device), stream))
+
+
 def sweep_device(model, n_vox, b, y, params, cost, g, jtj, device, stream=None):
     """Enqueue one residual/Jacobian/normal-equation sweep on HBM-resident torch tensors (f32 or f64)."""
     import torch

@@ -8,6 +8,8 @@
 
 #include <cmath>
 
+#include <hipcub/hipcub.hpp>
+
 #include "pnx_internal.hpp"
 
 namespace pnx {
@@ -103,6 +105,51 @@ __global__ void ideal_bounds_kernel(const double *__restrict__ map, long long n_
     }
 }
 
+// ---- level plumbing between the resize and the fit (IDEALFitter.fit, fitters/ideal.py:199-254): which voxels of the level
+// are fitted, their signal rows and start values gathered, the estimates scattered back into the level's map.
+struct MaskAbove {  // idx -> mask[idx] > thr   (ideal.py:199: `_segmentation_interp[..., 0] > self.segmentation_threshold`)
+    const double *mask;
+    double thr;
+    __host__ __device__ bool operator()(const long long &i) const { return mask[i] > thr; }
+};
+
+__global__ void gather_rows_kernel(const double *__restrict__ src, const long long *__restrict__ idx, long long n_sel, int c,
+                                   double *__restrict__ dst) {
+    const long long total = n_sel * c;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / c;
+        const int j = (int)(e - i * c);
+        dst[e] = src[idx[i] * c + j];
+    }
+}
+
+// pmap (n_total, k) zero filled before; pmap[idx[i]][j] = popt[j][i]  (idx == nullptr: identity)
+__global__ void scatter_rows_t_kernel(const double *__restrict__ popt, const long long *__restrict__ idx, long long n_sel, int k,
+                                      double *__restrict__ pmap) {
+    const long long total = n_sel * k;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / n_sel);
+        const long long i = e - (long long)j * n_sel;  // consecutive threads: consecutive voxels of one parameter row
+        pmap[(idx ? idx[i] : i) * k + j] = popt[e];
+    }
+}
+
+// sum_i (y_i - mean(y))^2 per row (fitters/base.py:179-181: SS_tot of R^2); one lane per row, rows are short (n_b values)
+__global__ void row_ss_tot_kernel(const double *__restrict__ y, long long n, int c, double *__restrict__ out) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const double *row = y + r * c;
+        double m = 0;
+        for (int j = 0; j < c; ++j) m += row[j];
+        m /= c;
+        double s = 0;
+        for (int j = 0; j < c; ++j) {
+            const double d = row[j] - m;
+            s = fma(d, d, s);
+        }
+        out[r] = s;
+    }
+}
+
 }  // namespace pnx
 
 using namespace pnx;
@@ -170,6 +217,91 @@ int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const do
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(ideal_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map, (long long)n_px, n_params, B, p0,
                        lower, upper);
+    RS_HIP(hipGetLastError());
+    return PNX_OK;
+}
+
+/* indices (C order) of the entries of `mask` (n values, device) that exceed `threshold`, written to idx (n int64, device);
+ * returns their number in *n_selected (host).  Synchronises `stream`: the caller sizes the level's arrays with the count. */
+int pnx_mask_select_f64(const double *mask, int64_t n, double threshold, int64_t *idx, int64_t *n_selected, int device,
+                        void *stream) {
+    if (!mask || !idx || !n_selected || n < 0) return set_error(PNX_ERR_INVALID, "bad argument");
+    *n_selected = 0;
+    if (n == 0) return PNX_OK;
+    RS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } tmp, cnt;
+    RS_HIP(hipMalloc(&cnt.p, sizeof(long long)));
+    MaskAbove pred{mask, threshold};
+    size_t bytes = 0;
+    // hipCUB takes an int count: levels beyond 2^31 voxels are cut into pieces
+    long long total = 0;
+    const int64_t piece = (int64_t)1 << 30;
+    for (int64_t off = 0; off < n; off += piece) {
+        const int m = (int)((n - off) < piece ? (n - off) : piece);
+        hipcub::CountingInputIterator<long long> it(off);
+        size_t need = 0;
+        RS_HIP(hipcub::DeviceSelect::If(nullptr, need, it, (long long *)idx + total, (long long *)cnt.p, m, pred, st));
+        if (!tmp.p || need > bytes) {
+            if (tmp.p) (void)hipFree(tmp.p);
+            tmp.p = nullptr;
+            RS_HIP(hipMalloc(&tmp.p, need ? need : 8));
+            bytes = need;
+        }
+        RS_HIP(hipcub::DeviceSelect::If(tmp.p, need, it, (long long *)idx + total, (long long *)cnt.p, m, pred, st));
+        long long c = 0;
+        RS_HIP(hipMemcpyAsync(&c, cnt.p, sizeof(c), hipMemcpyDeviceToHost, st));
+        RS_HIP(hipStreamSynchronize(st));
+        total += c;
+    }
+    *n_selected = total;
+    return PNX_OK;
+}
+
+/* dst (n_sel, c) = src[idx, :]  (src (n, c) row-major, idx (n_sel) int64; all device; enqueued only) */
+int pnx_gather_rows_f64(const double *src, int64_t c, const int64_t *idx, int64_t n_sel, double *dst, int device, void *stream) {
+    if (!src || !idx || !dst || c < 1 || c > (1 << 20) || n_sel < 0) return set_error(PNX_ERR_INVALID, "bad argument");
+    if (n_sel == 0) return PNX_OK;
+    RS_HIP(hipSetDevice(device));
+    size_t blocks = ((size_t)n_sel * c + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (const long long *)idx,
+                       (long long)n_sel, (int)c, dst);
+    RS_HIP(hipGetLastError());
+    return PNX_OK;
+}
+
+/* Parameter map of a level from the solver's estimates: pmap (n_total, k) = 0, then pmap[idx[i], j] = popt[j, i] for the n_sel
+ * fitted voxels (idx NULL: all voxels in order).  popt (k, n_sel) parameter major.  All device; enqueued only.
+ * (fitters/ideal.py:243-252: `param_map[xs, ys, zs, param_idx] = values`) */
+int pnx_scatter_rows_t_f64(const double *popt, const int64_t *idx, int64_t n_sel, int k, int64_t n_total, double *pmap, int device,
+                           void *stream) {
+    if (!popt || !pmap || k < 1 || n_sel < 0 || n_total < n_sel) return set_error(PNX_ERR_INVALID, "bad argument");
+    RS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (idx || n_sel < n_total) RS_HIP(hipMemsetAsync(pmap, 0, (size_t)n_total * k * sizeof(double), st));
+    if (n_sel == 0) return PNX_OK;
+    size_t blocks = ((size_t)n_sel * k + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(scatter_rows_t_kernel, dim3((unsigned)blocks), dim3(256), 0, st, popt, (const long long *)idx, (long long)n_sel, k,
+                       pmap);
+    RS_HIP(hipGetLastError());
+    return PNX_OK;
+}
+
+/* out (n) = sum_j (y[i, j] - mean_j y[i, :])^2: SS_tot of R^2 (fitters/base.py:179-183).  Device pointers; enqueued only. */
+int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int device, void *stream) {
+    if (!y || !out || n < 0 || c < 1) return set_error(PNX_ERR_INVALID, "bad argument");
+    if (n == 0) return PNX_OK;
+    RS_HIP(hipSetDevice(device));
+    size_t blocks = ((size_t)n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(row_ss_tot_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, (long long)n, c, out);
     RS_HIP(hipGetLastError());
     return PNX_OK;
 }

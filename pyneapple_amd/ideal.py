@@ -226,7 +226,9 @@ class HipIDEALFitter(HipFitterBase):
     def _fit_device(self, xdata, image, segmentation, dim_steps, names, p0_vals, lo_vals, hi_vals, tol_vals, t0, fit_kwargs):
         """Same level loop as above with everything between the first upload and the per-level map download in HBM:
         pnx_resize2d_f64 (image, mask, previous maps), pnx_ideal_bounds_f64 (p0 / bounds of the level) and the
-        device-pointer fit (pnx_curvefit_batch_f64, per-voxel p0 / bounds).  torch only allocates and indexes."""
+        device-pointer fit (pnx_curvefit_batch_f64, per-voxel p0 / bounds); mask thresholding + compaction, row gathers, the
+        map scatter and SS_tot are HIP kernels too (pnx_mask_select_f64, pnx_gather_rows_f64, pnx_scatter_rows_t_f64,
+        pnx_row_ss_tot_f64).  torch allocates, uploads and downloads; the level statistics use its reductions."""
         import torch
 
         from . import api
@@ -258,21 +260,29 @@ class HipIDEALFitter(HipFitterBase):
                 return dst
 
             img_l = resize(img_d, Z * N)
-            mask = resize(seg_d, Z) > self.segmentation_threshold
-            if not bool(mask.any()):
-                mask = torch.ones(shape, dtype=torch.bool, device=dev)
-            all_px = bool(mask.all())
-            idx = None if all_px else mask.reshape(-1).nonzero().squeeze(1)
-            n_px = tx * ty * Z if all_px else int(idx.numel())
-            pixels = img_l.reshape(-1, N) if all_px else img_l.reshape(-1, N).index_select(0, idx)
+            n_all = tx * ty * Z
+            # fitted voxels of the level: resized segmentation above the threshold (ideal.py:199), all voxels when the ROI
+            # does not survive the down-sampling (ideal.py:199-209) -- thresholding + stable compaction on the device
+            idx_buf = torch.empty(n_all, dtype=torch.int64, device=dev)
+            n_sel = api.mask_select_device(resize(seg_d, Z), self.segmentation_threshold, idx_buf, dev_i, stream)
+            all_px = n_sel == 0 or n_sel == n_all
+            idx = None if all_px else idx_buf[:n_sel]
+            n_px = n_all if all_px else n_sel
+            if all_px:
+                pixels = img_l.reshape(-1, N)
+            else:
+                pixels = torch.empty((n_px, N), dtype=torch.float64, device=dev)
+                api.gather_rows_device(img_l, N, idx, n_px, pixels, dev_i, stream)
             per_voxel = prev is not None
             if per_voxel:
                 m = resize(prev, Z * n).reshape(-1, n)
                 if not all_px:
-                    m = m.index_select(0, idx)
+                    mg = torch.empty((n_px, n), dtype=torch.float64, device=dev)
+                    api.gather_rows_device(m, n, idx, n_px, mg, dev_i, stream)
+                    m = mg
                 p0_d = torch.empty((n, n_px), dtype=torch.float64, device=dev)
                 lo_d, hi_d = torch.empty_like(p0_d), torch.empty_like(p0_d)
-                api.ideal_bounds_device(m.contiguous(), n_px, lo_vals, hi_vals, tol_vals, p0_d, lo_d, hi_d, dev_i, stream)
+                api.ideal_bounds_device(m, n_px, lo_vals, hi_vals, tol_vals, p0_d, lo_d, hi_d, dev_i, stream)
                 p0_a, lo_a, hi_a = p0_d, lo_d, hi_d
             else:
                 p0_a, lo_a, hi_a = p0_vals, lo_vals, hi_vals
@@ -285,7 +295,6 @@ class HipIDEALFitter(HipFitterBase):
             opts = api.make_opts(s._kernel_model, N, [], per_voxel, False, int(s.max_iter), float(s.tol), 1e-8, 1e-8,
                                  s.jacobian_mode, kw["t1_mode"], kw["tr"], kw["tm"])
             t_b = time.perf_counter()
-            pixels = pixels.contiguous()
             cost0 = None
             if per_voxel and kw["t1_mode"] == 0:
                 # cost at the level's start values: one pass of the HBM-streaming residual sweep (pnx_sweep_f64) over
@@ -307,12 +316,9 @@ class HipIDEALFitter(HipFitterBase):
             self.level_stats_.append(stats)
             if last and self.keep_level_inputs and per_voxel:
                 self.last_level_inputs_ = {"p0": p0_d, "lo": lo_d, "hi": hi_d, "idx": idx, "cost_p0": cost0}
-            if all_px:
-                pmap = popt.t().contiguous().reshape(tx, ty, Z, n)
-            else:
-                pmap = torch.zeros((tx * ty * Z, n), dtype=torch.float64, device=dev)
-                pmap.index_copy_(0, idx, popt.t().contiguous())
-                pmap = pmap.reshape(tx, ty, Z, n)
+            # the level's parameter map (ideal.py:243-252): estimates scattered to their voxels, zero elsewhere
+            pmap = torch.empty((tx, ty, Z, n), dtype=torch.float64, device=dev)
+            api.scatter_rows_t_device(popt, idx, n_px, n, n_all, pmap, dev_i, stream)
             torch.cuda.synchronize(dev)
             t_c = time.perf_counter()
             self.step_params.append(pmap.cpu().numpy())
@@ -320,12 +326,15 @@ class HipIDEALFitter(HipFitterBase):
             self.stage_times_.append((round(t_b - t_a, 3), round(t_c - t_b, 3), round(time.perf_counter() - t_c, 3)))
         res = {"popt": popt.cpu().numpy(), "pcov": pcov.cpu().numpy(), "status": status.cpu().numpy(),
                "nfev": nfev.cpu().numpy(), "cost": cost.cpu().numpy()}
-        ss_tot = (pixels.var(dim=1, unbiased=False) * N).cpu().numpy()  # SS_tot of the fitted rows, reduced in HBM
+        ss_d = torch.empty(n_px, dtype=torch.float64, device=dev)
+        api.row_ss_tot_device(pixels, n_px, N, ss_d, dev_i, stream)  # SS_tot of the fitted rows, reduced in HBM
+        ss_tot = ss_d.cpu().numpy()
         s._reset_state()
         s._pack(res, n_px, list(names))  # the solver ends in the state solver.fit() of the last level leaves it in
-        self.pixel_indices = (torch.ones(shape, dtype=torch.bool) if all_px else mask.cpu()).nonzero().numpy()
+        lin = np.arange(n_all) if all_px else idx.cpu().numpy()
+        self.pixel_indices = np.stack(np.unravel_index(lin, shape), axis=1)  # (n_px, 3), C order of np.where
         self.fitted_params_ = dict(s.params_)
         self.fit_time = time.perf_counter() - t0
-        host_pixels = image.reshape(-1, N) if all_px else image[mask.cpu().numpy()]
+        host_pixels = image.reshape(-1, N) if all_px else image.reshape(-1, N)[lin]
         self.results_ = self._assemble(xdata, host_pixels, self.fit_time, ss_tot=ss_tot)
         return self

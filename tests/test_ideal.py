@@ -265,3 +265,43 @@ def test_config5_triexp_three_levels_full_size(gpu, oracle):
     ss_res = ((ysub - pred) ** 2).sum(axis=1)
     ss_tot = ((ysub - ysub.mean(axis=1, keepdims=True)) ** 2).sum(axis=1)
     np.testing.assert_allclose(r2[sub][good], (1 - ss_res / ss_tot)[good], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_level_plumbing_kernels_match_numpy(gpu):
+    """pnx_mask_select_f64 / pnx_gather_rows_f64 / pnx_scatter_rows_t_f64 / pnx_row_ss_tot_f64 against the numpy statements
+    of the reference's level loop (fitters/ideal.py:199-254: threshold, `image[mask]`, `param_map[xs, ys, zs, k] = values`)."""
+    import torch
+
+    rng = np.random.default_rng(7)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for shape, thr in (((9, 7, 3), 0.2), ((64, 33, 5), 0.55), ((4, 4, 1), 2.0), ((4, 4, 1), -1.0)):
+        mask = rng.random(shape)
+        n_all = mask.size
+        md = torch.from_numpy(mask).to(dev)
+        idx = torch.empty(n_all, dtype=torch.int64, device=dev)
+        k = gpu.mask_select_device(md, thr, idx, 0, st)
+        want = np.flatnonzero(mask.reshape(-1) > thr)          # C order of np.where
+        assert k == len(want)
+        np.testing.assert_array_equal(idx[:k].cpu().numpy(), want)
+        if k == 0:
+            continue
+        c = 6
+        src = rng.normal(size=(n_all, c))
+        sd = torch.from_numpy(src).to(dev)
+        dst = torch.empty((k, c), dtype=torch.float64, device=dev)
+        gpu.gather_rows_device(sd, c, idx[:k], k, dst, 0, st)
+        np.testing.assert_array_equal(dst.cpu().numpy(), src[want])
+        popt = rng.normal(size=(3, k))                          # parameter major, as the solver returns it
+        pmap = torch.full((n_all, 3), 7.0, dtype=torch.float64, device=dev)
+        gpu.scatter_rows_t_device(torch.from_numpy(popt).to(dev), idx[:k], k, 3, n_all, pmap, 0, st)
+        ref = np.zeros((n_all, 3))
+        ref[want] = popt.T
+        np.testing.assert_array_equal(pmap.cpu().numpy(), ref)
+        pall = rng.normal(size=(3, n_all))
+        gpu.scatter_rows_t_device(torch.from_numpy(pall).to(dev), None, n_all, 3, n_all, pmap, 0, st)
+        np.testing.assert_array_equal(pmap.cpu().numpy(), pall.T)
+        ss = torch.empty(n_all, dtype=torch.float64, device=dev)
+        gpu.row_ss_tot_device(sd, n_all, c, ss, 0, st)
+        np.testing.assert_allclose(ss.cpu().numpy(), ((src - src.mean(axis=1, keepdims=True)) ** 2).sum(axis=1), rtol=1e-13)
