@@ -805,7 +805,7 @@ int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y
     if (max_iter <= 0) max_iter = 3 * P.n_bins;
     std::lock_guard<std::mutex> plan_lock(plan->mu);
     // spectra of one chunk live in device scratch only: solve -> peak analysis -> next chunk
-    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 18, 1024, 1 << 22);
+    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 20, 1024, 1 << 22);
     const size_t nv = (size_t)n_vox, cap = nv < chunk ? nv : chunk;
     DevBuf spec, stage;
     int rc;

@@ -13,9 +13,12 @@
 // _peak_widths with linear interpolation of the crossing points.  Pinned by fixtures generated from the reference
 // (tests/golden/g9_spectrum_*).
 //
-// Mapping: HBM-bound integer/compare work.  One lane owns one voxel; a wave stages its 64 spectra through LDS with
-// coalesced loads (row stride n_bins + 1: the per-lane row walks are bank-conflict free), then every lane runs the
-// sequential scans on its own row.  Outputs are written voxel major (a few doubles per voxel).
+// Mapping: HBM-bound compare / ballot work.  One wavefront owns one spectrum, four bins per lane: the row arrives with four
+// coalesced 512-byte loads, neighbour samples come from a 2 KB LDS copy, and SciPy's sequential scans become wave ballots
+// (nearest higher sample = highest / lowest set bit of a comparison mask, bases = masked wave minimum + ballot of the
+// equal samples, crossing points = highest / lowest set bit of `x <= height`).  The peak table of a voxel lives in lanes
+// 0..15.  A first version (one lane per spectrum walking an LDS tile of 64 spectra) ran at 101 GB/s: 1 500 dependent LDS
+// reads per lane with one wave per CU; spectra with a flat-topped rise still take that sequential path (one lane).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -43,173 +46,345 @@ struct PeakArgs {
     double *f_cut;
 };
 
-__global__ void __launch_bounds__(kW) spectrum_peaks_kernel(const PeakArgs A) {
-    extern __shared__ double tile[];  // [64][n_bins + 1]
-    const int lane = threadIdx.x;
-    const int n = A.n_bins, st = n + 1;
+// One voxel, one lane, SciPy's loops as they are written (plateaus included).  The wave-parallel kernel below falls back
+// to this for the rare spectrum with a flat-topped rise (equal neighbouring samples after a rise), where the midpoint rule
+// needs the sequential scan.
+__device__ void peaks_sequential(const PeakArgs &A, const double *x, long long vox) {
+    const int n = A.n_bins;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    for (long long v0 = (long long)blockIdx.x * kW; v0 < A.n_vox; v0 += (long long)gridDim.x * kW) {
-        const int rows = (A.n_vox - v0) < kW ? (int)(A.n_vox - v0) : kW;
-        __syncthreads();
-        // coalesced stage: element e of the (rows x n) block, consecutive lanes consecutive addresses
-        const double *src = A.spec + (size_t)v0 * n;
-        for (int e = lane; e < rows * n; e += kW) {
-            const int r = e / n, c = e - r * n;
-            tile[r * st + c] = src[e];
-        }
-        __syncthreads();
-        if (lane >= rows) continue;
-        const double *x = tile + lane * st;
-        const long long vox = v0 + lane;
-
-        // ---- scipy.signal._peak_finding_utils._local_maxima_1d + the height condition (hmin <= x[peak])
-        int pk[kMaxPeaks];
-        int m = 0, total = 0;
-        {
-            int i = 1;
-            const int i_max = n - 1;
-            while (i < i_max) {
-                if (x[i - 1] < x[i]) {
-                    int ia = i + 1;
-                    while (ia < i_max && x[ia] == x[i]) ++ia;
-                    if (x[ia] < x[i]) {
-                        const int mid = (i + ia - 1) / 2;
-                        if (A.height <= x[mid]) {
-                            if (m < kMaxPeaks) {
+    // ---- scipy.signal._peak_finding_utils._local_maxima_1d + the height condition (hmin <= x[peak])
+    int pk[kMaxPeaks];
+    int m = 0, total = 0;
+    {
+        int i = 1;
+        const int i_max = n - 1;
+        while (i < i_max) {
+            if (x[i - 1] < x[i]) {
+                int ia = i + 1;
+                while (ia < i_max && x[ia] == x[i]) ++ia;
+                if (x[ia] < x[i]) {
+                    const int mid = (i + ia - 1) / 2;
+                    if (A.height <= x[mid]) {
+                        if (m < kMaxPeaks) {
 #pragma unroll
-                                for (int k = 0; k < kMaxPeaks; ++k)
-                                    if (k == m) pk[k] = mid;  // static indexing: the list stays in registers
-                                ++m;
-                            }
-                            ++total;
+                            for (int k = 0; k < kMaxPeaks; ++k)
+                                if (k == m) pk[k] = mid;  // static indexing: the list stays in registers
+                            ++m;
                         }
-                        i = ia;
+                        ++total;
                     }
+                    i = ia;
                 }
-                ++i;
             }
+            ++i;
         }
-        // ---- fractions: raw heights, or the Gaussian area from the width at rel_height of the prominence
-        double fv[kMaxPeaks], dv[kMaxPeaks];
-        double fsum = 0;
+    }
+    // ---- fractions: raw heights, or the Gaussian area from the width at rel_height of the prominence
+    double fv[kMaxPeaks], dv[kMaxPeaks];
+    double fsum = 0;
 #pragma unroll
-        for (int k = 0; k < kMaxPeaks; ++k) {
-            fv[k] = nan;
-            dv[k] = nan;
-            if (k < m) {
-                const int peak = pk[k];
-                const double xp = x[peak];
-                double f = xp;
-                if (A.regularized) {
-                    // _peak_prominences, wlen = None
-                    int i = peak, lb = peak, rb = peak;
-                    double lmin = xp, rmin = xp;
-                    while (0 <= i && x[i] <= xp) {
-                        if (x[i] < lmin) {
-                            lmin = x[i];
-                            lb = i;
-                        }
-                        --i;
+    for (int k = 0; k < kMaxPeaks; ++k) {
+        fv[k] = nan;
+        dv[k] = nan;
+        if (k < m) {
+            const int peak = pk[k];
+            const double xp = x[peak];
+            double f = xp;
+            if (A.regularized) {
+                // _peak_prominences, wlen = None
+                int i = peak, lb = peak, rb = peak;
+                double lmin = xp, rmin = xp;
+                while (0 <= i && x[i] <= xp) {
+                    if (x[i] < lmin) {
+                        lmin = x[i];
+                        lb = i;
                     }
-                    i = peak;
-                    while (i <= n - 1 && x[i] <= xp) {
-                        if (x[i] < rmin) {
-                            rmin = x[i];
-                            rb = i;
-                        }
-                        ++i;
-                    }
-                    const double prom = xp - fmax(lmin, rmin);
-                    // _peak_widths
-                    const double h = xp - prom * A.rel_height;
-                    i = peak;
-                    while (lb < i && h < x[i]) --i;
-                    double lip = (double)i;
-                    if (x[i] < h) lip += (h - x[i]) / (x[i + 1] - x[i]);
-                    i = peak;
-                    while (i < rb && h < x[i]) ++i;
-                    double rip = (double)i;
-                    if (x[i] < h) rip -= (h - x[i]) / (x[i - 1] - x[i]);
-                    const double fwhm = rip - lip;
-                    // spectrum.py:44-47: height * fwhm / (2 sqrt(2 ln 2)) * sqrt(2 pi)
-                    f = xp * fwhm / (2.0 * sqrt(2.0 * log(2.0))) * sqrt(2.0 * 3.141592653589793);
+                    --i;
                 }
-                fv[k] = f;
-                dv[k] = A.bins[peak];
-                fsum += f;
-            }
-        }
-        if (fsum > 0) {
-#pragma unroll
-            for (int k = 0; k < kMaxPeaks; ++k)
-                if (k < m) fv[k] = fv[k] / fsum;
-        }
-        if (A.n_peaks) A.n_peaks[vox] = total;
-        if (A.d_values) {
-            for (int k = 0; k < A.max_peaks; ++k) {
-                double d = nan, f = nan;
-#pragma unroll
-                for (int j = 0; j < kMaxPeaks; ++j)
-                    if (j == k) {
-                        d = dv[j];
-                        f = fv[j];
+                i = peak;
+                while (i <= n - 1 && x[i] <= xp) {
+                    if (x[i] < rmin) {
+                        rmin = x[i];
+                        rb = i;
                     }
-                A.d_values[(size_t)vox * A.max_peaks + k] = d;
-                A.f_values[(size_t)vox * A.max_peaks + k] = f;
+                    ++i;
+                }
+                const double prom = xp - fmax(lmin, rmin);
+                // _peak_widths
+                const double h = xp - prom * A.rel_height;
+                i = peak;
+                while (lb < i && h < x[i]) --i;
+                double lip = (double)i;
+                if (x[i] < h) lip += (h - x[i]) / (x[i + 1] - x[i]);
+                i = peak;
+                while (i < rb && h < x[i]) ++i;
+                double rip = (double)i;
+                if (x[i] < h) rip -= (h - x[i]) / (x[i - 1] - x[i]);
+                const double fwhm = rip - lip;
+                // spectrum.py:44-47: height * fwhm / (2 sqrt(2 ln 2)) * sqrt(2 pi)
+                f = xp * fwhm / (2.0 * sqrt(2.0 * log(2.0))) * sqrt(2.0 * 3.141592653589793);
             }
+            fv[k] = f;
+            dv[k] = A.bins[peak];
+            fsum += f;
         }
-        // ---- apply_cutoffs (spectrum.py:142-215): none -> NaN, one -> as is, several -> geometric_mean_peak
-        if (A.d_cut) {
-            double dc[kMaxCut], fc[kMaxCut];
-            double tot = 0;
-            bool any = false;
+    }
+    if (fsum > 0) {
 #pragma unroll
-            for (int c = 0; c < kMaxCut; ++c) {
-                dc[c] = nan;
-                fc[c] = nan;
-                if (c < A.n_cut) {
-                    const double lo = A.cut[2 * c], hi = A.cut[2 * c + 1];
-                    int cnt = 0;
-                    double hs = 0, d1 = 0, f1 = 0;
+        for (int k = 0; k < kMaxPeaks; ++k)
+            if (k < m) fv[k] = fv[k] / fsum;
+    }
+    if (A.n_peaks) A.n_peaks[vox] = total;
+    if (A.d_values) {
+        for (int k = 0; k < A.max_peaks; ++k) {
+            double d = nan, f = nan;
+#pragma unroll
+            for (int j = 0; j < kMaxPeaks; ++j)
+                if (j == k) {
+                    d = dv[j];
+                    f = fv[j];
+                }
+            A.d_values[(size_t)vox * A.max_peaks + k] = d;
+            A.f_values[(size_t)vox * A.max_peaks + k] = f;
+        }
+    }
+    // ---- apply_cutoffs (spectrum.py:142-215): none -> NaN, one -> as is, several -> geometric_mean_peak
+    if (A.d_cut) {
+        double dc[kMaxCut], fc[kMaxCut];
+        double tot = 0;
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < kMaxCut; ++c) {
+            dc[c] = nan;
+            fc[c] = nan;
+            if (c < A.n_cut) {
+                const double lo = A.cut[2 * c], hi = A.cut[2 * c + 1];
+                int cnt = 0;
+                double hs = 0, d1 = 0, f1 = 0;
+#pragma unroll
+                for (int k = 0; k < kMaxPeaks; ++k)
+                    if (k < m && dv[k] >= lo && dv[k] <= hi) {
+                        ++cnt;
+                        hs += fv[k];
+                        d1 = dv[k];
+                        f1 = fv[k];
+                    }
+                if (cnt == 1) {
+                    dc[c] = d1;
+                    fc[c] = f1;
+                } else if (cnt > 1) {
+                    // geometric_mean_peak (spectrum.py:106-139): log10(prod(pos ** (h / sum h))), sum h
+                    double prod = 1.0;
 #pragma unroll
                     for (int k = 0; k < kMaxPeaks; ++k)
-                        if (k < m && dv[k] >= lo && dv[k] <= hi) {
-                            ++cnt;
-                            hs += fv[k];
-                            d1 = dv[k];
-                            f1 = fv[k];
-                        }
-                    if (cnt == 1) {
-                        dc[c] = d1;
-                        fc[c] = f1;
-                    } else if (cnt > 1) {
-                        // geometric_mean_peak (spectrum.py:106-139): log10(prod(pos ** (h / sum h))), sum h
-                        double prod = 1.0;
-#pragma unroll
-                        for (int k = 0; k < kMaxPeaks; ++k)
-                            if (k < m && dv[k] >= lo && dv[k] <= hi) prod *= pow(dv[k], fv[k] / hs);
-                        dc[c] = log10(prod);
-                        fc[c] = hs;
-                    }
-                    if (cnt > 0) {
-                        tot += fc[c];
-                        any = true;
-                    }
+                        if (k < m && dv[k] >= lo && dv[k] <= hi) prod *= pow(dv[k], fv[k] / hs);
+                    dc[c] = log10(prod);
+                    fc[c] = hs;
+                }
+                if (cnt > 0) {
+                    tot += fc[c];
+                    any = true;
                 }
             }
-            for (int c = 0; c < A.n_cut; ++c) {
-                double d = nan, f = nan;
+        }
+        for (int c = 0; c < A.n_cut; ++c) {
+            double d = nan, f = nan;
 #pragma unroll
-                for (int j = 0; j < kMaxCut; ++j)
-                    if (j == c) {
-                        d = dc[j];
-                        f = fc[j];
+            for (int j = 0; j < kMaxCut; ++j)
+                if (j == c) {
+                    d = dc[j];
+                    f = fc[j];
+                }
+            if (any && tot > 0 && !isnan(f)) f = f / tot;
+            A.d_cut[(size_t)vox * A.n_cut + c] = d;
+            A.f_cut[(size_t)vox * A.n_cut + c] = f;
+        }
+    }
+}
+
+// ---- wave-parallel version: one wavefront owns one spectrum, four bins per lane (bin = 64 s + lane) ---------------
+__device__ inline double wmin(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+struct Mask4 {  // one bit per bin
+    unsigned long long m[4];
+};
+__device__ inline Mask4 ballot4(const bool (&c)[4]) {
+    Mask4 r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r.m[s] = __ballot(c[s] ? 1 : 0);
+    return r;
+}
+__device__ inline int highest(const Mask4 &k) {  // index of the highest set bit, -1 if none
+#pragma unroll
+    for (int s = 3; s >= 0; --s)
+        if (k.m[s]) return 64 * s + 63 - __builtin_clzll(k.m[s]);
+    return -1;
+}
+__device__ inline int lowest(const Mask4 &k, int none) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (k.m[s]) return 64 * s + __builtin_ctzll(k.m[s]);
+    return none;
+}
+
+__global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
+    __shared__ double rows[4][kMaxBins + 8];  // per wave: the spectrum, one pad sample on either side
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = A.n_bins;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    double *xr = rows[wave] + 1;  // xr[-1] and xr[n] exist
+    for (long long vox = (long long)blockIdx.x * 4 + wave; vox < A.n_vox; vox += (long long)gridDim.x * 4) {
+        const double *src = A.spec + (size_t)vox * n;
+        double v[4];
+        int j[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            j[s] = 64 * s + lane;
+            v[s] = j[s] < n ? src[j[s]] : 0.0;  // coalesced: 512 bytes per instruction
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xr[j[s]] = v[s];
+        if (lane == 0) {
+            xr[-1] = 0.0;
+            xr[n] = 0.0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS instructions execute in order
+        // ---- _local_maxima_1d without plateaus + the height condition
+        bool pk[4], flat[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool in = j[s] >= 1 && j[s] <= n - 2;
+            const double xm = xr[j[s] - 1], xp = in ? xr[j[s] + 1] : 0.0;
+            const bool rise = in && xm < v[s];
+            pk[s] = rise && v[s] > xp && A.height <= v[s];
+            flat[s] = rise && v[s] == xp;
+        }
+        if (__any((flat[0] || flat[1] || flat[2] || flat[3]) ? 1 : 0)) {
+            if (lane == 0) peaks_sequential(A, xr, vox);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            continue;
+        }
+        Mask4 peaks = ballot4(pk);
+        const int total = __popcll(peaks.m[0]) + __popcll(peaks.m[1]) + __popcll(peaks.m[2]) + __popcll(peaks.m[3]);
+        // peak k of the list lives in lane k
+        double dval = nan, fval = nan;
+        int m = 0;
+        for (int s = 0; s < 4; ++s) {
+            unsigned long long bits = peaks.m[s];
+            while (bits && m < kMaxPeaks) {
+                const int p = 64 * s + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const double xp = xr[p];
+                double f = xp;
+                if (A.regularized) {
+                    // _peak_prominences (wlen = None): nearest higher sample on either side bounds the scan; the base is the
+                    // lowest sample in between, the one closest to the peak among equals
+                    bool c[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] < p && v[t] > xp;
+                    const int L = highest(ballot4(c));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] > p && j[t] < n && v[t] > xp;
+                    const int R = lowest(ballot4(c), n);
+                    double a = INFINITY, b = INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (j[t] > L && j[t] <= p) a = fmin(a, v[t]);
+                        if (j[t] >= p && j[t] < R) b = fmin(b, v[t]);
                     }
-                if (any && tot > 0 && !isnan(f)) f = f / tot;
-                A.d_cut[(size_t)vox * A.n_cut + c] = d;
-                A.f_cut[(size_t)vox * A.n_cut + c] = f;
+                    const double lmin = wmin(a), rmin = wmin(b);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] > L && j[t] <= p && v[t] == lmin;
+                    const int lb = highest(ballot4(c));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] >= p && j[t] < R && v[t] == rmin;
+                    const int rb = lowest(ballot4(c), p);
+                    const double prom = xp - fmax(lmin, rmin);
+                    // _peak_widths: first sample at or below the evaluation height on either side, not beyond the bases
+                    const double h = xp - prom * A.rel_height;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] > lb && j[t] <= p && !(h < v[t]);
+                    int li = highest(ballot4(c));
+                    if (li < 0) li = lb;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) c[t] = j[t] >= p && j[t] < rb && !(h < v[t]);
+                    const int ri = lowest(ballot4(c), rb);
+                    double lip = (double)li, rip = (double)ri;
+                    const double xl = xr[li], xrr = xr[ri];
+                    if (xl < h) lip += (h - xl) / (xr[li + 1] - xl);
+                    if (xrr < h) rip -= (h - xrr) / (xr[ri - 1] - xrr);
+                    const double fwhm = rip - lip;
+                    f = xp * fwhm / (2.0 * sqrt(2.0 * log(2.0))) * sqrt(2.0 * 3.141592653589793);  // spectrum.py:44-47
+                }
+                if (lane == m) {
+                    dval = A.bins[p];
+                    fval = f;
+                }
+                ++m;
             }
         }
+        {   // np.sum of the fractions in peak order, then the normalisation (spectrum.py:96-99)
+            double fsum = 0;
+            for (int k = 0; k < m; ++k) fsum += __shfl(fval, k);
+            if (fsum > 0 && lane < m) fval = fval / fsum;
+        }
+        if (A.n_peaks && lane == 0) A.n_peaks[vox] = total;
+        if (A.d_values && lane < A.max_peaks) {
+            A.d_values[(size_t)vox * A.max_peaks + lane] = dval;
+            A.f_values[(size_t)vox * A.max_peaks + lane] = fval;
+        }
+        // ---- apply_cutoffs (spectrum.py:142-215)
+        if (A.d_cut) {
+            double dc = nan, fc = nan;  // range c lives in lane c
+            double tot = 0;
+            bool any = false;
+            for (int c = 0; c < A.n_cut; ++c) {
+                const double lo = A.cut[2 * c], hi = A.cut[2 * c + 1];
+                const bool in = lane < m && dval >= lo && dval <= hi;
+                const unsigned long long bits = __ballot(in ? 1 : 0);
+                const int cnt = __popcll(bits);
+                double d = nan, f = nan;
+                if (cnt == 1) {
+                    const int k = __builtin_ctzll(bits);
+                    d = __shfl(dval, k);
+                    f = __shfl(fval, k);
+                } else if (cnt > 1) {
+                    // geometric_mean_peak (spectrum.py:106-139): sums and the product run over the peaks in order
+                    double hs = 0;
+                    for (unsigned long long b2 = bits; b2; b2 &= b2 - 1) hs += __shfl(fval, __builtin_ctzll(b2));
+                    double prod = 1.0;
+                    for (unsigned long long b2 = bits; b2; b2 &= b2 - 1) {
+                        const int k = __builtin_ctzll(b2);
+                        prod *= pow(__shfl(dval, k), __shfl(fval, k) / hs);
+                    }
+                    d = log10(prod);
+                    f = hs;
+                }
+                if (cnt > 0) {
+                    tot += f;
+                    any = true;
+                }
+                if (lane == c) {
+                    dc = d;
+                    fc = f;
+                }
+            }
+            if (any && tot > 0 && !isnan(fc)) fc = fc / tot;
+            if (lane < A.n_cut) {
+                A.d_cut[(size_t)vox * A.n_cut + lane] = dc;
+                A.f_cut[(size_t)vox * A.n_cut + lane] = fc;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row buffer is rewritten by the next voxel
     }
 }
 
@@ -303,16 +478,10 @@ int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectru
             a.f_cut = (double *)dfc.p;
         }
     }
-    const size_t lds = sizeof(double) * kW * (n_bins + 1);
-    static bool attr_done[64] = {false};
-    if (!attr_done[device & 63]) {
-        PNX_HIPS(hipFuncSetAttribute((const void *)spectrum_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * kW * (kMaxBins + 1))));
-        attr_done[device & 63] = true;
-    }
-    long long grid = (n_vox + kW - 1) / kW;
+    long long grid = (n_vox + 3) / 4;
     const long long cap = (long long)prop.multiProcessorCount * 8;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(spectrum_peaks_kernel, dim3((unsigned)grid), dim3(kW), lds, st, a);
+    hipLaunchKernelGGL(spectrum_peaks_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
     PNX_HIPS(hipGetLastError());
     if (mem == PNX_MEM_HOST) {
         if (n_peaks) PNX_HIPS(hipMemcpyAsync(n_peaks, a.n_peaks, nv * sizeof(int32_t), hipMemcpyDeviceToHost, st));
