@@ -287,7 +287,7 @@ def timed(leg, steps, warmup, world, dist, torch):
     kernel_ms = [a.elapsed_time(b) for a, b in ev]  # HIP events on the launch stream
     from pyneapple_amd.sharding import max_over_ranks
 
-    dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
+    dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda" if dist is None or dist.get_backend() == "nccl" else "cpu")
     return dt, kernel_ms
 
 
@@ -438,6 +438,10 @@ def main(argv=None):
         print(json.dumps({"rank": rank, "world": world, "local_rank": local, "rows": rows, "n_vox_total": n_total}), flush=True)
         return 0
 
+    # stdout carries exactly ONE JSON line: whatever libraries print there (gloo / RCCL connection notes, ...) is sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     from pyneapple_amd import _lib
@@ -445,14 +449,22 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # rehearsal knobs (one-GPU box): PNX_BENCH_SHARE_GPU=1 puts every rank on device 0, PNX_BENCH_BACKEND=gloo carries the
+    # barrier / max-reduce over the CPU -- the driver's multi-GPU runs use neither
+    share = os.environ.get("PNX_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("PNX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL; only used for the barrier and the max-reduce
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL; only used for the barrier and the max-reduce
+        else:
+            dist.init_process_group(backend)
         world = dist.get_world_size()
     _lib.load()
 
@@ -539,7 +551,8 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     return 0
 
 
