@@ -377,6 +377,84 @@ def main_g9():
             print(f"{name}: peaks/voxel mean {n_peaks.mean():.2f} max {n_peaks.max()}")
 
 
+def main_g10():
+    """Fifth batch (round 2): the two remaining callers of the solver path -- SegmentedFitter (two chained pixel-wise fits,
+    fitters/segmented.py:159-242) and SegmentationWiseFitter (one fit per label on the mean signal,
+    fitters/segmentationwise.py:43-139)."""
+    from pyneapple import BiExpModel, CurveFitSolver, MonoExpModel, SegmentationWiseFitter, SegmentedFitter
+
+    rng = np.random.default_rng(SEED + 10)
+    b = np.array([0, 10, 20, 40, 60, 80, 100, 150, 200, 300, 400, 500, 600, 700, 800, 1000], float)
+    shape = (6, 5, 2)
+    f1 = rng.uniform(0.1, 0.4, shape)
+    D1 = rng.uniform(1e-2, 5e-2, shape)
+    D2 = rng.uniform(5e-4, 2e-3, shape)
+    S0 = rng.uniform(0.8, 1.2, shape)
+    img = S0[..., None] * (f1[..., None] * np.exp(-b * D1[..., None]) + (1 - f1[..., None]) * np.exp(-b * D2[..., None]))
+    img = img * (1.0 + 0.005 * rng.standard_normal(img.shape))
+    seg = np.zeros(shape, dtype=int)
+    seg[1:5, :, :] = 1
+    seg[2, 2, 0] = 0
+    mono_p0, mono_bd = {"S0": 1.0, "D": 0.001}, {"S0": (0.0, 5.0), "D": (0.0, 0.01)}
+    bi_p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001, "S0": 1.0}
+    bi_bd = {"f1": (0.0, 1.0), "D1": (0.003, 0.1), "D2": (0.0, 0.005), "S0": (0.1, 5.0)}
+
+    def two_step(fixed, mapping, rng_b):
+        s1 = CurveFitSolver(model=MonoExpModel(), max_iter=200, tol=1e-8, p0=mono_p0, bounds=mono_bd)
+        s2 = CurveFitSolver(model=BiExpModel(fit_reduced=True, fit_s0=True), max_iter=500, tol=1e-8, p0=bi_p0, bounds=bi_bd)
+        fit = SegmentedFitter(step1_solver=s1, step2_solver=s2, step1_bvalue_range=rng_b, fixed_from_step1=fixed,
+                              param_mapping=mapping)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fit.fit(b, img, segmentation=seg)
+        r, r1 = fit.results_, fit.step1_result_
+        names = list(fit.fitted_params_)
+        return dict(bvalues=b, image=img, segmentation=seg, pixel_indices=np.array(fit.pixel_indices),
+                    param_names=np.array(names), params=np.stack([np.asarray(fit.fitted_params_[n]) for n in names]),
+                    step1_names=np.array(list(fit.step1_params_)),
+                    step1_params=np.stack([np.asarray(v) for v in fit.step1_params_.values()]),
+                    step1_success=r1.success, success=r.success, r_squared=r.r_squared,
+                    result_param_names=np.array(list(r.params)), covariance_shape=np.array(r.covariance.shape),
+                    fixed_from_step1=np.array(fixed), mapping_src=np.array(list(mapping)),
+                    mapping_dst=np.array(list(mapping.values())),
+                    bvalue_lo=np.nan if rng_b is None or rng_b[0] is None else rng_b[0],
+                    bvalue_hi=np.nan if rng_b is None or rng_b[1] is None else rng_b[1], **_versions())
+
+    out = two_step(["D"], {"D": "D2"}, (200, None))
+    np.savez_compressed(os.path.join(OUT, "g10_segmented_fix_D.npz"), **out)
+    print(f"g10_segmented_fix_D: names={list(out['param_names'])} success={out['success'].mean():.3f}")
+    out = two_step([], {}, None)
+    np.savez_compressed(os.path.join(OUT, "g10_segmented_nofix.npz"), **out)
+    print(f"g10_segmented_nofix: names={list(out['param_names'])} success={out['success'].mean():.3f}")
+
+    # --- SegmentationWiseFitter: labels 0..3 (0 is fitted too: np.unique keeps it), with and without a fixed map
+    lab = rng.integers(0, 4, shape)
+    lab[0, 0, 0] = 7                      # a label with one voxel, and a gap in the label values
+    for tag, fixed_maps in (("", None), ("_fixedmap", {"D1": D1})):
+        s = CurveFitSolver(model=BiExpModel(fit_reduced=True, fit_s0=True), max_iter=500, tol=1e-8, p0=bi_p0, bounds=bi_bd)
+        fit = SegmentationWiseFitter(s)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fit.fit(b, img, segmentation=lab, fixed_param_maps=fixed_maps)
+        names = list(fit.fitted_params_)
+        try:
+            pred, predict_raises = fit.predict(b), False
+        except KeyError:      # with a fixed map the reference's predict() indexes fitted_params_ with the fixed name
+            pred, predict_raises = np.zeros(0), True
+        extra = {"predict_raises": np.array(predict_raises)}
+        if fixed_maps is not None:
+            extra["fixed_D1"] = D1
+        np.savez_compressed(os.path.join(OUT, f"g10_segmentationwise{tag}.npz"), bvalues=b, image=img, segmentation=lab,
+                            segment_labels=fit.segment_labels, param_names=np.array(names),
+                            params=np.stack([np.asarray(fit.fitted_params_[n]) for n in names]),
+                            pixel_indices=np.array(fit.pixel_indices), predict=pred,
+                            success=fit.results_.success, n_pixels=fit.results_.n_pixels,
+                            p0_names=np.array(list(bi_p0)), p0_vals=np.array(list(bi_p0.values())),
+                            lo_vals=np.array([v[0] for v in bi_bd.values()]), hi_vals=np.array([v[1] for v in bi_bd.values()]),
+                            **extra, **_versions())
+        print(f"g10_segmentationwise{tag}: labels={fit.segment_labels} names={names}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
@@ -391,6 +469,12 @@ if __name__ == "__main__":
         _install_shims()
         os.makedirs(OUT, exist_ok=True)
         main_g9()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g10":
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        main_g10()
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
         sys.dont_write_bytecode = True

@@ -166,3 +166,69 @@ def test_xtol_gtol_solver_kwargs_reach_the_kernel(gpu, oracle):
         got = np.stack([s.params_[n] for n in names])
         rel = np.abs(got - ref["popt"]) / np.maximum(np.abs(ref["popt"]), 1e-300)
         assert (rel.max(axis=0) <= 1e-4).mean() >= 0.99
+
+
+class TestReferenceContractOddsAndEnds:
+    """The remaining behaviours the reference's solver tests pin (tests/test_solver_curvefit.py:597-640,811-840;
+    tests/test_solver_nnls.py:463-560,663-735)."""
+
+    def test_fit_returns_self_and_key_order(self, gpu):
+        s = mono_solver()
+        assert s.fit(B8, 1000.0 * np.exp(-B8 * 1e-3)) is s
+        assert list(s.get_params().keys()) == s.model.param_names
+
+    def test_identical_voxels_give_identical_results(self, gpu):
+        y = np.tile(1000.0 * np.exp(-B8 * 1e-3), (5, 1))
+        s = mono_solver().fit(B8, y)
+        assert np.ptp(s.params_["S0"]) == 0.0 and np.ptp(s.params_["D"]) == 0.0  # same lanes' arithmetic, bit for bit
+
+    @pytest.mark.parametrize("noise_std", [1.0, 10.0, 50.0])
+    def test_noisy_data_within_tolerance(self, gpu, noise_std):
+        rng = np.random.default_rng(42)
+        y = 1000.0 * np.exp(-B8 * 1e-3) + rng.normal(0, noise_std, B8.size)
+        s = mono_solver().fit(B8, y)
+        assert s.params_["S0"][0] == pytest.approx(1000.0, rel=noise_std / 1000.0 * 20) and s.params_["D"][0] > 0
+
+    def test_diagnostics_are_copies(self, gpu):
+        s = mono_solver().fit(B8, 1000.0 * np.exp(-B8 * 1e-3))
+        d = s.get_diagnostics()
+        d["n_pixels"] = 99
+        assert s.diagnostics_["n_pixels"] == 1
+
+    @pytest.mark.parametrize("fit_reduced,fit_s0,names", [(False, False, ["f1", "D1", "f2", "D2"]),
+                                                          (True, False, ["f1", "D1", "D2"]),
+                                                          (True, True, ["f1", "D1", "D2", "S0"])])
+    def test_biexp_modes_param_count(self, gpu, fit_reduced, fit_s0, names):
+        m = BiExpModel(fit_reduced=fit_reduced, fit_s0=fit_s0)
+        assert m.param_names == names
+        b = np.linspace(0, 1200, 24)
+        y = 0.3 * np.exp(-b * 0.02) + 0.7 * np.exp(-b * 1e-3)
+        p0 = {"f1": 0.2, "D1": 0.01, "f2": 0.8, "D2": 0.001, "S0": 1.0}
+        bd = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "f2": (0.0, 1.0), "D2": (1e-5, 5e-3), "S0": (0.1, 10.0)}
+        s = HipCurveFitSolver(model=m, max_iter=250, tol=1e-8, p0={k: p0[k] for k in names},
+                              bounds={k: bd[k] for k in names}).fit(b, y)
+        assert list(s.params_) == names and s.diagnostics_["pcov"].shape == (len(names), len(names))
+        assert s.params_["D2"][0] == pytest.approx(1e-3, rel=1e-3)
+
+    @pytest.mark.parametrize("reg_order", [0, 1, 2, 3])
+    def test_nnls_completes_for_all_reg_orders(self, gpu, reg_order):
+        b = np.array([0, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 250, 350, 450, 550, 650], float)
+        y = 0.3 * np.exp(-b * 0.05) + 0.7 * np.exp(-b * 0.001)
+        s = HipNNLSSolver(model=NNLSModel(d_range=(1e-4, 0.1), n_bins=50), reg_order=reg_order, mu=0.02)
+        assert s.fit(b, y) is s
+        c = s.params_["coefficients"]
+        assert c.shape == (1, 50) and (c >= 0).all() and s.diagnostics_["residual"].shape == (1,)
+
+    def test_nnls_results_are_copies_and_refit_resets(self, gpu):
+        b = np.linspace(0, 1000, 16)
+        y = np.tile(np.exp(-b * 2e-3), (3, 1))
+        s = HipNNLSSolver(model=NNLSModel(d_range=(1e-4, 0.1), n_bins=50), reg_order=2, mu=0.02).fit(b, y)
+        p = s.get_params()
+        p["coefficients"] = np.zeros((1, 1))
+        assert s.params_["coefficients"].shape == (3, 50)
+        r0 = s.diagnostics_["residual"].copy()
+        d = s.get_diagnostics()
+        d["residual"] = np.array([99999.0])
+        np.testing.assert_array_equal(s.diagnostics_["residual"], r0)
+        s.fit(b, y[:1])
+        assert s.params_["coefficients"].shape == (1, 50) and s.diagnostics_["residual"].shape == (1,)
