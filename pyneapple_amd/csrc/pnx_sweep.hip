@@ -227,6 +227,73 @@ __global__ void __launch_bounds__(256) sweep_kernel(const SweepArgs<T> A) {
 }
 
 
+#ifndef PNX_SWEEP_PACKED
+#define PNX_SWEEP_PACKED 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Row pass of the fp32 triexp (reduced) sweep with the instruction count cut for the VALU: at 45 instructions per row the
+// pass costs more issue time than its 232 B per voxel cost HBM time.  Here: diffusivities pre-multiplied by -log2(e)
+// (v_exp_f32 is 2^x), b-values straight from the kernel argument (scalar registers, no LDS reads), and the 21 accumulations
+// -- the upper triangle of v v^T for v = [J_f1, J_f2, J_D1, J_D2, J_D3, r] -- as 9 packed FMAs on register pairs that the
+// evaluation produces as pairs + 3 scalar ones: 26 VALU instructions per row.  Outputs in the ABI's parameter order
+// [f1, D1, f2, D2, D3].
+template <int NB>
+__device__ __forceinline__ void tri_rows_packed(const float *p, const float *row, const float *b, float &cost, float *g, float *H) {
+    constexpr float L2E = 1.4426950408889634f;
+    const v2f d12 = {-p[1] * L2E, -p[3] * L2E};
+    const float d3 = -p[4] * L2E;
+    const v2f f12 = {p[0], p[2]};
+    const float f3 = 1.0f - p[0] - p[2];
+    const v2f z = {0.0f, 0.0f};
+    v2f a00 = z, a02 = z, a04 = z, a12 = z, a14 = z, a22 = z, a24 = z, a34 = z, a44 = z;
+    float s11 = 0.0f, s33 = 0.0f, srr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float bb = b[i];
+        const v2f x12 = d12 * bb;
+        const float x3 = d3 * bb;
+        v2f e12;
+        e12.x = __builtin_amdgcn_exp2f(x12.x);
+        e12.y = __builtin_amdgcn_exp2f(x12.y);
+        const float e3 = __builtin_amdgcn_exp2f(x3);
+        const v2f t12 = f12 * e12;
+        const float t3 = f3 * e3;
+        const float r = (t12.x + t12.y) + t3 - row[i];
+        const v2f v01 = e12 - e3;            // J_f1, J_f2
+        const v2f v23 = t12 * (-bb);         // J_D1, J_D2
+        v2f v4r;
+        v4r.x = t3 * (-bb);                  // J_D3
+        v4r.y = r;
+        a00 += v01.x * v01;
+        a02 += v01.x * v23;
+        a04 += v01.x * v4r;
+        s11 += v01.y * v01.y;
+        a12 += v01.y * v23;
+        a14 += v01.y * v4r;
+        a22 += v23.x * v23;
+        a24 += v23.x * v4r;
+        s33 += v23.y * v23.y;
+        a34 += v23.y * v4r;
+        a44 += v4r.x * v4r;
+        srr += r * r;
+    }
+    // internal order [f1, f2, D1, D2, D3] -> output order [f1, D1, f2, D2, D3]; H row-major upper triangle of 5 x 5
+    cost = srr;
+    H[0] = a00.x;  H[2] = a00.y;            // (f1,f1) (f1,f2)
+    H[1] = a02.x;  H[3] = a02.y;            // (f1,D1) (f1,D2)
+    H[4] = a04.x;  g[0] = a04.y;            // (f1,D3)
+    H[9] = s11;                             // (f2,f2)
+    H[6] = a12.x;  H[10] = a12.y;           // (D1,f2) (f2,D2)
+    H[11] = a14.x; g[2] = a14.y;            // (f2,D3)
+    H[5] = a22.x;  H[7] = a22.y;            // (D1,D1) (D1,D2)
+    H[8] = a24.x;  g[1] = a24.y;            // (D1,D3)
+    H[12] = s33;                            // (D2,D2)
+    H[13] = a34.x; g[3] = a34.y;            // (D2,D3)
+    H[14] = a44.x; g[4] = a44.y;            // (D3,D3)
+}
+
+
 // Full-tile fast path: n_b is the compile-time NB, every tile holds 64 voxels, so the tile copy is CH = NB / VEC
 // unpredicated 16-byte loads per lane.  Software pipeline per wave: the loads of tile t+1 (signal chunks AND the
 // parameter vector) are issued right after tile t has been scattered into LDS and before its row loop, so nothing the
@@ -285,23 +352,27 @@ __global__ void __launch_bounds__(256) sweep_full_kernel(const SweepArgs<T> A, c
             for (int k = 0; k < NALL; ++k) pn[k] = A.params[(size_t)k * A.n_vox + tn * kWave + lane];
         }
         T cost = 0, g[NALL], H[NTRI];
-#pragma unroll
-        for (int k = 0; k < NALL; ++k) g[k] = 0;
-#pragma unroll
-        for (int k = 0; k < NTRI; ++k) H[k] = 0;
         const T *row = tile + lane * STRIDE;
+        if constexpr (MODEL == 4 && sizeof(T) == 4 && PNX_SWEEP_PACKED) {
+            tri_rows_packed<NB>(p, row, A.b, cost, g, H);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NALL; ++k) g[k] = 0;
+#pragma unroll
+            for (int k = 0; k < NTRI; ++k) H[k] = 0;
 #pragma unroll 8
-        for (int i = 0; i < NB; ++i) {
-            T sig, ja[NALL];
-            MT::eval(p, bsh[i], sig, ja);
-            const T r = sig - row[i];
-            cost += r * r;
-            int q = 0;
+            for (int i = 0; i < NB; ++i) {
+                T sig, ja[NALL];
+                MT::eval(p, bsh[i], sig, ja);
+                const T r = sig - row[i];
+                cost += r * r;
+                int q = 0;
 #pragma unroll
-            for (int a = 0; a < NALL; ++a) {
-                g[a] += ja[a] * r;
+                for (int a = 0; a < NALL; ++a) {
+                    g[a] += ja[a] * r;
 #pragma unroll
-                for (int c = a; c < NALL; ++c) H[q++] += ja[a] * ja[c];
+                    for (int c = a; c < NALL; ++c) H[q++] += ja[a] * ja[c];
+                }
             }
         }
         st_out<NT>(A.cost + vox, T(0.5) * cost);
