@@ -333,7 +333,13 @@ def pmc_flops(kernel_prefix: str, group: str):
     return None
 
 
-def mfma_roofline(device, torch, reps=20):
+# Launches of the two sub-millisecond roofline kernels before their timed regions: a burst of 20 launches from an idle GPU
+# (4 ms) runs 10-15 % slower per launch than the sustained rate (groups of 20: 0.181-0.198 ms, groups of 500: 0.171 ms for the
+# sweep, profiles/sweep_sustain.py) -- the clocks are still ramping.  30 warm-up launches, then >= 100 timed ones.
+WARM_LAUNCHES = 30
+
+
+def mfma_roofline(device, torch, reps=100):
     """The NNLS Gram step (aty = y . basis on v_mfma_f64_16x16x4) alone, 2^20 voxels x 32 b-values x 250 bins:
     algorithmic flops 2 * n_vox * n_b * n_bins per launch against the fp64 matrix peak."""
     from pyneapple_amd import api, synth
@@ -344,7 +350,7 @@ def mfma_roofline(device, torch, reps=20):
     _, y = synth.make_torch("tri_reduced", n_vox, n_b, device, sigma=0.01, scale=1000.0)
     aty = torch.empty((n_vox, 256), dtype=torch.float64, device=device)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
+    for _ in range(WARM_LAUNCHES):
         plan.aty_device(n_vox, y, aty, stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -367,7 +373,7 @@ def mfma_roofline(device, torch, reps=20):
                     "materialised, so the step is co-bound by its HBM write"}
 
 
-def sweep_roofline(device, torch, n_vox_override=0, reps=20):
+def sweep_roofline(device, torch, n_vox_override=0, reps=300):
     """The LM residual/Jacobian/normal-equation sweep as a standalone HBM-streaming kernel (pnx_sweep_f32),
     triexp on the C3 volume: 232 algorithmic bytes per voxel-sweep against the HBM roofline."""
     from pyneapple_amd import api, synth
@@ -384,11 +390,11 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=20):
     g = torch.empty((n, n_vox), dtype=torch.float32, device=device)
     h = torch.empty((ntri, n_vox), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
+    for _ in range(WARM_LAUNCHES):
         api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
     torch.cuda.synchronize()
     # one HIP-event pair per launch (on the launch stream): the average launch duration, free of host-side gaps
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(reps, 50))]
     for e0, e1 in evs:
         e0.record()
         api.sweep_device(model, n_vox, b, y, params, cost, g, h, device.index, stream)
