@@ -252,6 +252,17 @@ int pnx_scatter_rows_t_f64(const double *popt, const int64_t *idx, int64_t n_sel
 int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int device, void *stream);
 
 /*
+ * Bulk copies between pageable host arrays and device buffers -- what torch's tensor.to(device) / tensor.cpu() (or a plain
+ * hipMemcpy) do for the callers that keep a volume resident across calls (the IDEAL level driver: fitters/ideal.py:226-259
+ * holds image, masks and maps in host arrays; here they live in HBM and cross PCIe once each way).  The range is cut into
+ * 32 MiB pieces (PNX_COPY_PIECE_MB) copied by `threads` host threads (0 = PNX_COPY_THREADS, default 4) on their own streams, a
+ * download touches its destination pages first.  Both synchronise `stream` before they start and return when the bytes have
+ * landed.
+ */
+int pnx_upload(void *dst_device, const void *src_host, int64_t bytes, int device, void *stream, int threads);
+int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int device, void *stream, int threads);
+
+/*
  * Residual / Jacobian / normal-equation sweep at given parameters (one pass of the LM inner loop as a
  * standalone, HBM-streaming kernel): for every voxel reads y (n_b) and params (n_all), writes
  * cost = 0.5*||r||^2, g = J^T r (n_all) and the upper triangle of J^T J (n_all(n_all+1)/2).

@@ -306,6 +306,32 @@ def row_ss_tot_device(y, n, c, out, device, stream=None):
     check(load().pnx_row_ss_tot_f64(ptr(y), int(n), int(c), ptr(out), int(device), stream))
 
 
+def upload(array, tensor, device, stream=None, threads=0):
+    """Host numpy array -> device tensor of the same byte size (pnx_upload: a few threads, 32 MiB pieces)."""
+    a = np.ascontiguousarray(array)
+    nbytes = int(tensor.numel()) * int(tensor.element_size())
+    if a.nbytes != nbytes:
+        raise ValueError(f"upload: {a.nbytes} host bytes into a {nbytes}-byte tensor")
+    check(load().pnx_upload(ptr(tensor), ptr(a), nbytes, int(device), stream, int(threads)))
+    return tensor
+
+
+def download(tensor, device, stream=None, threads=0, dtype=None):
+    """Contiguous device tensor -> fresh numpy array of the same shape (pnx_download: destination pages touched ahead of the
+    copy, a few threads).  dtype: numpy dtype of the result (default: from the tensor's element size and kind)."""
+    import torch
+
+    if not tensor.is_contiguous():
+        tensor = tensor.contiguous()
+    if dtype is None:
+        dtype = {torch.float64: np.float64, torch.float32: np.float32, torch.int8: np.int8, torch.int32: np.int32,
+                 torch.int64: np.int64, torch.uint8: np.uint8}[tensor.dtype]
+    out = np.empty(tuple(tensor.shape), dtype=dtype)
+    if out.nbytes:
+        check(load().pnx_download(ptr(out), ptr(tensor), out.nbytes, int(device), stream, int(threads)))
+    return out
+
+
 def sweep_device(model, n_vox, b, y, params, cost, g, jtj, device, stream=None):
     """Enqueue one residual/Jacobian/normal-equation sweep on HBM-resident torch tensors (f32 or f64)."""
     import torch

@@ -305,3 +305,30 @@ def test_level_plumbing_kernels_match_numpy(gpu):
         ss = torch.empty(n_all, dtype=torch.float64, device=dev)
         gpu.row_ss_tot_device(sd, n_all, c, ss, 0, st)
         np.testing.assert_allclose(ss.cpu().numpy(), ((src - src.mean(axis=1, keepdims=True)) ** 2).sum(axis=1), rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_bulk_copies_round_trip(gpu):
+    """pnx_upload / pnx_download: bytes arrive unchanged for sizes below, at and across the 32 MiB piece boundary, with one
+    or several threads; a size mismatch is refused on the host side."""
+    import torch
+
+    from pyneapple_amd import api
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    for n, threads in ((0, 0), (1, 1), (1000, 0), ((32 << 20) // 8, 2), ((80 << 20) // 8 + 13, 0), ((80 << 20) // 8 + 13, 1)):
+        a = rng.standard_normal(n)
+        t = torch.empty(n, dtype=torch.float64, device=dev)
+        if n:
+            api.upload(a, t, 0, torch.cuda.current_stream().cuda_stream, threads)
+        np.testing.assert_array_equal(t.cpu().numpy(), a)
+        t2 = torch.from_numpy(a).to(dev) * 2.0          # produced on the stream the download has to wait for
+        back = api.download(t2, 0, torch.cuda.current_stream().cuda_stream, threads)
+        np.testing.assert_array_equal(back, a * 2.0)
+    i8 = torch.arange(-100, 100, dtype=torch.int8, device=dev)
+    np.testing.assert_array_equal(api.download(i8, 0), np.arange(-100, 100, dtype=np.int8))
+    m = torch.arange(24, dtype=torch.float64, device=dev).reshape(4, 6).t()   # non-contiguous view
+    np.testing.assert_array_equal(api.download(m, 0), np.arange(24.0).reshape(4, 6).T)
+    with pytest.raises(ValueError):
+        api.upload(np.zeros(3), torch.empty(4, dtype=torch.float64, device=dev), 0)
