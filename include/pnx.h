@@ -263,6 +263,16 @@ int pnx_upload(void *dst_device, const void *src_host, int64_t bytes, int device
 int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int device, void *stream, int threads);
 
 /*
+ * Per-label column sums of an (n, c) row matrix and the rows per label: the reduction SegmentationWiseFitter performs with a
+ * boolean gather + np.mean per label before it fits one row per label (fitters/segmentationwise.py:101-123).  labels[i] in
+ * [0, n_labels) is the row's label POSITION (np.unique order); rows with a label outside that range are skipped.
+ * sums (n_labels, c), counts (n_labels).  Deterministic (fixed summation order, no atomics).  mem: host pointers (the rows are
+ * uploaded with pnx_upload's threaded copy) or device pointers; n_labels * (c + 1) <= 8192.  Synchronises the stream.
+ */
+int pnx_label_sums_f64(const double *rows, const int32_t *labels, int64_t n, int c, int n_labels, double *sums, int64_t *counts,
+                       int mem, int device, void *stream);
+
+/*
  * Residual / Jacobian / normal-equation sweep at given parameters (one pass of the LM inner loop as a
  * standalone, HBM-streaming kernel): for every voxel reads y (n_b) and params (n_all), writes
  * cost = 0.5*||r||^2, g = J^T r (n_all) and the upper triangle of J^T J (n_all(n_all+1)/2).

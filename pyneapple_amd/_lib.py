@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
     "pnx_resize2d_f64", "pnx_ideal_bounds_f64", "pnx_nnls_spectrum_peaks_f64", "pnx_nnls_solve_peaks_f64", "pnx_scatter_maps_f32",
     "pnx_mask_select_f64", "pnx_gather_rows_f64", "pnx_scatter_rows_t_f64", "pnx_row_ss_tot_f64", "pnx_upload", "pnx_download",
+    "pnx_label_sums_f64",
 ]
 
 
@@ -139,6 +140,8 @@ def load():
     lib.pnx_scatter_rows_t_f64.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int64, vp, C.c_int, vp]
     lib.pnx_row_ss_tot_f64.restype = C.c_int
     lib.pnx_row_ss_tot_f64.argtypes = [vp, C.c_int64, C.c_int, vp, C.c_int, vp]
+    lib.pnx_label_sums_f64.restype = C.c_int
+    lib.pnx_label_sums_f64.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]
     for f in (lib.pnx_upload, lib.pnx_download):
         f.restype = C.c_int
         f.argtypes = [vp, vp, C.c_int64, C.c_int, vp, C.c_int]

@@ -306,6 +306,22 @@ def row_ss_tot_device(y, n, c, out, device, stream=None):
     check(load().pnx_row_ss_tot_f64(ptr(y), int(n), int(c), ptr(out), int(device), stream))
 
 
+LABEL_TABLE_MAX = 8192  # n_labels * (c + 1) entries of the kernel's 64 KB LDS table
+
+
+def label_sums(rows, label_pos, n_labels, device=0):
+    """(sums (n_labels, c), counts (n_labels,)) of the rows per label position (host arrays in and out, pnx_label_sums_f64)."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    lab = np.ascontiguousarray(label_pos, np.int32)
+    n, c = rows.shape
+    if lab.shape != (n,):
+        raise ValueError(f"label_pos must have shape ({n},), got {lab.shape}")
+    sums = np.empty((int(n_labels), c))
+    counts = np.empty(int(n_labels), dtype=np.int64)
+    check(load().pnx_label_sums_f64(ptr(rows), ptr(lab), n, c, int(n_labels), ptr(sums), ptr(counts), MEM_HOST, int(device), None))
+    return sums, counts
+
+
 def upload(array, tensor, device, stream=None, threads=0):
     """Host numpy array -> device tensor of the same byte size (pnx_upload: a few threads, 32 MiB pieces)."""
     a = np.ascontiguousarray(array)

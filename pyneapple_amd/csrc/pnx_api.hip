@@ -999,3 +999,120 @@ int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int devi
 }
 
 }  // extern "C"
+
+// ---- per-label sums of an (n, c) row matrix: the reduction in front of a segmentation-wise fit ---------------------
+// Deterministic on purpose (no atomics): wave w owns a contiguous range of rows and adds them, in order, into its own LDS
+// table [n_labels][c] (lane k owns column k); a second kernel adds the per-wave tables in wave order.
+namespace pnx {
+constexpr int kLabelWaves = 2048;
+constexpr int kLabelUnroll = 8;
+
+__global__ void __launch_bounds__(64) label_partial_kernel(const double *img, const int32_t *lab, long long n, int c, int n_lab,
+                                                           double *part, long long *cnt_part) {
+    extern __shared__ double tab[];  // [n_lab][c] doubles, then n_lab counts
+    long long *cnt = reinterpret_cast<long long *>(tab + (size_t)n_lab * c);
+    const int lane = threadIdx.x;
+    for (int e = lane; e < n_lab * c; e += 64) tab[e] = 0.0;
+    for (int e = lane; e < n_lab; e += 64) cnt[e] = 0;
+    __syncthreads();
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long v0 = (long long)blockIdx.x * per;
+    const long long v1 = (v0 + per) < n ? (v0 + per) : n;
+    for (int k0 = 0; k0 < c; k0 += 64) {  // one pass per 64 columns (c <= 64: a single pass)
+        const int k = k0 + lane;
+        const bool on = k < c;
+        long long v = v0;
+        for (; v + kLabelUnroll <= v1; v += kLabelUnroll) {
+            int l[kLabelUnroll];
+            double x[kLabelUnroll];
+#pragma unroll
+            for (int u = 0; u < kLabelUnroll; ++u) {  // the loads of eight rows are in flight together
+                l[u] = lab[v + u];
+                x[u] = on ? img[(size_t)(v + u) * c + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kLabelUnroll; ++u) {
+                if ((unsigned)l[u] < (unsigned)n_lab) {
+                    if (on) tab[(size_t)l[u] * c + k] += x[u];
+                    if (k0 == 0 && lane == 0) cnt[l[u]] += 1;
+                }
+            }
+        }
+        for (; v < v1; ++v) {
+            const int l = lab[v];
+            if ((unsigned)l < (unsigned)n_lab) {
+                if (on) tab[(size_t)l * c + k] += img[(size_t)v * c + k];
+                if (k0 == 0 && lane == 0) cnt[l] += 1;
+            }
+        }
+    }
+    __syncthreads();
+    double *dst = part + (size_t)blockIdx.x * n_lab * c;
+    for (int e = lane; e < n_lab * c; e += 64) dst[e] = tab[e];
+    for (int e = lane; e < n_lab; e += 64) cnt_part[(size_t)blockIdx.x * n_lab + e] = cnt[e];
+}
+
+__global__ void label_reduce_kernel(const double *part, const long long *cnt_part, int waves, int n_lab, int c, double *sums,
+                                    long long *counts) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_lab * c) {
+        double s = 0.0;
+        for (int w = 0; w < waves; ++w) s += part[(size_t)w * n_lab * c + e];
+        sums[e] = s;
+    }
+    if (e < n_lab) {
+        long long m = 0;
+        for (int w = 0; w < waves; ++w) m += cnt_part[(size_t)w * n_lab + e];
+        counts[e] = m;
+    }
+}
+}  // namespace pnx
+
+extern "C" int pnx_label_sums_f64(const double *rows, const int32_t *labels, int64_t n, int c, int n_labels, double *sums,
+                                  int64_t *counts, int mem, int device, void *stream) {
+    using namespace pnx;
+    if (n < 0 || c < 1 || n_labels < 1) return set_error(PNX_ERR_INVALID, "bad label-sum sizes (n=%lld, c=%d, n_labels=%d)", (long long)n, c, n_labels);
+    if (!sums || !counts || (n && (!rows || !labels))) return set_error(PNX_ERR_INVALID, "NULL pointer");
+    if (mem != PNX_MEM_HOST && mem != PNX_MEM_DEVICE) return set_error(PNX_ERR_INVALID, "mem must be PNX_MEM_HOST or PNX_MEM_DEVICE");
+    const size_t lds = ((size_t)n_labels * c + n_labels) * sizeof(double);
+    if (lds > 64 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_labels * (c + 1) = %zu entries do not fit the 64 KB LDS table", lds / 8);
+    DeviceInfo *dev;
+    int rc = get_device(device, &dev);
+    if (rc) return rc;
+    PNX_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool host = mem == PNX_MEM_HOST;
+    const size_t tab = (size_t)n_labels * c;
+    int waves = (int)((n + 63) / 64);
+    if (waves > kLabelWaves) waves = kLabelWaves;
+    if (waves < 1) waves = 1;
+    DevBuf d_rows, d_lab, d_part, d_cnt, d_sums, d_counts;
+    if ((rc = d_part.alloc((size_t)waves * tab * sizeof(double))) || (rc = d_cnt.alloc((size_t)waves * n_labels * sizeof(long long)))) return rc;
+    const double *rows_d = rows;
+    const int32_t *lab_d = labels;
+    double *sums_d = sums;
+    long long *counts_d = reinterpret_cast<long long *>(counts);
+    if (host) {
+        if ((rc = d_rows.alloc((size_t)n * c * sizeof(double))) || (rc = d_lab.alloc((size_t)n * sizeof(int32_t))) ||
+            (rc = d_sums.alloc(tab * sizeof(double))) || (rc = d_counts.alloc((size_t)n_labels * sizeof(long long))))
+            return rc;
+        if ((rc = bulk_copy(d_rows.p, rows, (size_t)n * c * sizeof(double), true, device, st, 0))) return rc;
+        if ((rc = bulk_copy(d_lab.p, labels, (size_t)n * sizeof(int32_t), true, device, st, 0))) return rc;
+        rows_d = (const double *)d_rows.p;
+        lab_d = (const int32_t *)d_lab.p;
+        sums_d = (double *)d_sums.p;
+        counts_d = (long long *)d_counts.p;
+    }
+    hipLaunchKernelGGL(label_partial_kernel, dim3(waves), dim3(64), lds, st, rows_d, lab_d, (long long)n, c, n_labels,
+                       (double *)d_part.p, (long long *)d_cnt.p);
+    PNX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(label_reduce_kernel, dim3((unsigned)((tab + 255) / 256)), dim3(256), 0, st, (const double *)d_part.p,
+                       (const long long *)d_cnt.p, waves, n_labels, c, sums_d, counts_d);
+    PNX_HIP(hipGetLastError());
+    if (host) {
+        PNX_HIP(hipMemcpyAsync(sums, sums_d, tab * sizeof(double), hipMemcpyDeviceToHost, st));
+        PNX_HIP(hipMemcpyAsync(counts, counts_d, (size_t)n_labels * sizeof(long long), hipMemcpyDeviceToHost, st));
+    }
+    PNX_HIP(hipStreamSynchronize(st));  // the scratch tables are freed on return
+    return PNX_OK;
+}

@@ -5,9 +5,10 @@
 `HipSegmentationWiseFitter` one fit per segmentation label on the label's mean signal (reference:
                            fitters/segmentationwise.py:19-179).
 
-Neither adds device code: the first is two batched solver calls whose second takes the first's result columns as its
-per-voxel fixed columns (same mask, same voxel order, so no volume round trip in between); the second reduces the image to
-a handful of rows before the solver sees it.  Both register under `pyneapple.fitters` like the pixel-wise fitter.
+The first is two batched solver calls whose second takes the first's result columns as its per-voxel fixed columns (same
+mask, same voxel order); the second reduces the image to a handful of rows before the solver sees it -- on the device
+(pnx_label_sums_f64: per-label column sums in a fixed order), with the label bookkeeping as array operations instead of the
+reference's per-voxel dictionary.  Both register under `pyneapple.fitters` like the pixel-wise fitter.
 """
 from __future__ import annotations
 
@@ -106,6 +107,37 @@ class HipSegmentedFitter(HipFitterBase):
         return list(self.solver.model._all_param_names)
 
 
+def _label_positions(segmentation):
+    """(labels in np.unique order, position of every voxel's label in that list) -- through a histogram when the labels are
+    small non-negative integers (the usual ROI mask), through np.unique otherwise."""
+    flat = np.asarray(segmentation).reshape(-1)
+    if flat.size and np.issubdtype(flat.dtype, np.integer) and flat.min() >= 0 and flat.max() < (1 << 20):
+        hist = np.bincount(flat)
+        labels = np.nonzero(hist)[0].astype(flat.dtype)
+        lut = np.full(hist.size, -1, dtype=np.int32)
+        lut[labels] = np.arange(labels.size, dtype=np.int32)
+        return labels, lut[flat]
+    labels, inv = np.unique(flat, return_inverse=True)
+    return labels, inv.reshape(-1).astype(np.int32)
+
+
+def _label_means(rows, inv, n_seg, device):
+    """Mean row per label position and the voxel counts.  On the GPU (pnx_label_sums_f64: fixed summation order) whenever the
+    per-wave table fits its LDS; a label set too large for that is reduced with one numpy histogram per column."""
+    from . import _lib, api
+
+    c = rows.shape[1]
+    if n_seg * (c + 1) <= api.LABEL_TABLE_MAX and _lib.device_count() > 0:
+        sums, counts = api.label_sums(rows, inv, n_seg, device)
+        counts = counts.astype(np.float64)
+        return sums / counts[:, None], counts
+    counts = np.bincount(inv, minlength=n_seg).astype(np.float64)
+    means = np.empty((n_seg, c))
+    for k in range(c):
+        means[:, k] = np.bincount(inv, weights=rows[:, k], minlength=n_seg) / counts
+    return means, counts
+
+
 class HipSegmentationWiseFitter(HipFitterBase):
     """fit(xdata, image, segmentation, fixed_param_maps=None): one solver row per label (np.unique order, label 0 included),
     each the mean signal of the label's voxels; a fixed map contributes its mean over the label.  `fitted_params_[name]` has
@@ -136,15 +168,13 @@ class HipSegmentationWiseFitter(HipFitterBase):
             raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {spatial}.")
         self.n_measurements = len(xdata)
         self.image_shape = image.shape
-        labels, inv = np.unique(segmentation, return_inverse=True)
-        inv = inv.reshape(-1)
+        labels, inv = _label_positions(segmentation)
         n_seg = labels.size
-        counts = np.bincount(inv, minlength=n_seg).astype(np.float64)
         flat = np.ascontiguousarray(image.reshape(-1, image.shape[-1]), dtype=np.float64)
-        means = np.empty((n_seg, xdata.size))
-        for k in range(xdata.size):                      # one pass per measurement; the image may be 1 GB
-            means[:, k] = np.bincount(inv, weights=flat[:, k], minlength=n_seg) / counts
-        order = np.argsort(inv, kind="stable")           # voxels label by label, C order inside a label
+        means, counts = _label_means(flat, inv, n_seg, getattr(self.solver, "device", 0))
+        # voxels label by label, C order inside a label: a stable sort of small unsigned keys is a radix sort in numpy
+        key = inv.astype(np.uint8 if n_seg <= 256 else np.uint16 if n_seg <= 65536 else np.int64)
+        order = np.argsort(key, kind="stable")
         self.segment_labels = labels
         self.segment_of_pixel = inv[order]
         self.pixel_indices = np.stack(np.unravel_index(order, spatial), axis=1)
