@@ -508,7 +508,19 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
 
     // ---- host staging: chunk ring (run_pipeline above)
     const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", 3 << 18, 1024, 1 << 26);
-    const int n_chunks = (int)((nv + chunk - 1) / chunk);
+    // chunk boundaries: with three or more full chunks the first and the last piece are a quarter chunk -- the first kernel
+    // starts after a quarter of an upload, and the serial tail (last kernel, last download) is a quarter as long
+    std::vector<size_t> bounds;
+    {
+        const size_t ramp = env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk ? chunk / 4 : 0;
+        size_t v = 0;
+        bounds.push_back(0);
+        if (ramp) bounds.push_back(v = ramp);
+        const size_t body_end = nv - ramp;
+        while (v < body_end) bounds.push_back(v = (body_end - v) < chunk ? body_end : v + chunk);
+        if (ramp) bounds.push_back(nv);
+    }
+    const int n_chunks = (int)bounds.size() - 1;
     const int n_slots = n_chunks < 3 ? n_chunks : env_int("PNX_HOST_SLOTS", 3, 2, 8);
     const size_t cap = nv < chunk ? nv : chunk;
     const bool need_stat = status || pcov, need_cost = cost || pcov;
@@ -549,8 +561,8 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         }
     }
     auto span = [&](int k, size_t &v0, size_t &c) {
-        v0 = (size_t)k * chunk;
-        c = (nv - v0) < chunk ? (nv - v0) : chunk;
+        v0 = bounds[k];
+        c = bounds[k + 1] - v0;
     };
     PipeOps ops;
     ops.h2d = [&](int k, int slot, hipStream_t st) -> int {
