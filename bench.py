@@ -549,7 +549,9 @@ def main(argv=None):
                                  nnls_traffic(leg.n_vox) if (args.workload == "nnls" and not args.voxels and world == 1) else None),
                      "algorithmic_bytes_per_launch": leg.bytes_per_voxel * leg.n_vox,
                      "algorithmic_bytes_per_voxel": leg.bytes_per_voxel, "kernel_ms_avg": k_avg * 1e3,
-                     "note": "whole-fit kernels are fp64-VALU bound, not HBM bound (DESIGN.md section 4); rank 0's kernel"},
+                     "note": "whole-fit kernels are fp64-VALU bound, not HBM bound (DESIGN.md section 4); rank 0's kernel; "
+                             "kernel_ms_avg covers the K one-at-a-time launches of the timed region -- the launches of the "
+                             "pipelined leg overlap in pairs and last about twice as long each (profiles: --no-pipelined)"},
         "check": leg.check(),
     }
     fl = pmc_flops(CURVEFIT_C3_KERNEL, "curvefit") if (args.workload == "triexp" and args.jac == "fd") else None
