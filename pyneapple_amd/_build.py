@@ -29,7 +29,7 @@ NNLS_FLAGS = os.environ.get("PNX_NNLS_FLAGS", "").split()  # e.g. -DPNX_NNLS_GBA
 # measured on, and bench.py only replays counters whose stamp matches the sources it is running
 SOURCE_GROUPS = {
     "curvefit": ["pnx_curvefit_kernel.hpp", "pnx_curvefit_inst.hip"],
-    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp", "pnx_nnls_qr.hip"],
+    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp", "pnx_nnls_dev.hpp", "pnx_nnls_qr.hip", "pnx_nnls_blk.hip"],
     "sweep": ["pnx_sweep.hip"],
 }
 
@@ -51,6 +51,7 @@ def source_ids() -> dict:
 
 def _units():
     units = [("pnx_api.o", "pnx_api.hip", []), ("pnx_nnls.o", "pnx_nnls.hip", NNLS_FLAGS), ("pnx_nnls_qr.o", "pnx_nnls_qr.hip", NNLS_FLAGS),
+             ("pnx_nnls_blk.o", "pnx_nnls_blk.hip", NNLS_FLAGS),
              ("pnx_sweep.o", "pnx_sweep.hip", []), ("pnx_spectrum.o", "pnx_spectrum.hip", []),
              ("pnx_resize.o", "pnx_resize.hip", [])]
     for m in range(N_MODELS):
@@ -69,23 +70,47 @@ def _compile(unit):
     obj, src, extra = unit
     cmd = [HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode == 0:
+        with open(os.path.join(OBJ, obj + ".cmd"), "w") as fh:
+            fh.write(" ".join(cmd))
     return obj, r.returncode, (r.stdout + r.stderr)
 
 
+def _stale(unit, force: bool) -> bool:
+    """An object is rebuilt when it is missing, older than its source or any header, or was compiled
+    with another command line (so a one-kernel edit recompiles one translation unit, not the seven curve-fit ones)."""
+    obj, src, extra = unit
+    o = os.path.join(OBJ, obj)
+    if force or not os.path.exists(o):
+        return True
+    cmd = " ".join([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", o])
+    try:
+        with open(o + ".cmd") as fh:
+            if fh.read() != cmd:
+                return True
+    except OSError:
+        return True
+    deps = [os.path.join(CSRC, src), os.path.join(HERE, "..", "include", "pnx.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    if src.startswith("pnx_curvefit") or src in ("pnx_sweep.hip", "pnx_spectrum.hip", "pnx_resize.hip"):
+        deps = [d for d in deps if "pnx_nnls" not in os.path.basename(d)]  # these units include no NNLS header
+    return max(os.path.getmtime(d) for d in deps) > os.path.getmtime(o)
+
+
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
-    newest = max(os.path.getmtime(p) for p in _deps())
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
-        return LIB
     os.makedirs(OBJ, exist_ok=True)
     units = _units()
-    jobs = jobs or min(len(units), max(1, (os.cpu_count() or 2)))
+    todo = [u for u in units if _stale(u, force)]
+    objs = [os.path.join(OBJ, u[0]) for u in units]
+    if not todo and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(o) for o in objs):
+        return LIB
+    jobs = jobs or min(max(1, len(todo)), max(1, (os.cpu_count() or 2)))
     with cf.ThreadPoolExecutor(jobs) as ex:
-        for obj, rc, out in ex.map(_compile, units):
+        for obj, rc, out in ex.map(_compile, todo):
             if verbose or rc:
                 sys.stderr.write(f"[pnx build] {obj}: rc={rc}\n{out}\n")
             if rc:
                 raise RuntimeError(f"hipcc failed for {obj}")
-    objs = [os.path.join(OBJ, u[0]) for u in units]
     cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:

@@ -31,11 +31,10 @@
 
 #include "pnx_internal.hpp"
 #include "pnx_nnls.hpp"
+#include "pnx_nnls_dev.hpp"
 
 namespace pnx {
 
-constexpr int kW = 64;
-constexpr int kSlots = kNnlsMaxBins / kW;  // 4
 #ifndef PNX_NNLS_LDS_ROWS
 #define PNX_NNLS_LDS_ROWS 48
 #endif
@@ -48,7 +47,6 @@ constexpr int kSlots = kNnlsMaxBins / kW;  // 4
 constexpr int kLdsRows = PNX_NNLS_LDS_ROWS;  // rows of M kept in LDS (<= 64)
 constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
-constexpr int kNone = 1 << 30;
 constexpr int kGBatch = PNX_NNLS_GBATCH;  // rows of G in flight per lane in the dual update
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
@@ -71,152 +69,6 @@ struct NnlsArgs {
 };
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
-
-// ---- cross-lane primitives ----------------------------------------------------------------------
-// DPP (row_shr 1/2/4/8, row_bcast 15/31): a handful of VALU ops with register-file latency instead of a dozen
-// ds_bpermute round trips per fp64 reduction.
-template <int CTRL, int ROW_MASK, bool ZERO_FILL> __device__ inline double dpp_mov(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int olo = ZERO_FILL ? 0 : lo, ohi = ZERO_FILL ? 0 : hi;
-    const int rlo = __builtin_amdgcn_update_dpp(olo, lo, CTRL, ROW_MASK, 0xf, ZERO_FILL);
-    const int rhi = __builtin_amdgcn_update_dpp(ohi, hi, CTRL, ROW_MASK, 0xf, ZERO_FILL);
-    return __hiloint2double(rhi, rlo);
-}
-template <int CTRL, int ROW_MASK> __device__ inline int dpp_mov_i(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
-}
-constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118, kBc15 = 0x142, kBc31 = 0x143;
-
-// v_readlane of a double; `l` must be wave-uniform
-__device__ inline double rl(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// inclusive prefix sum over the 64 lanes (lane 63 holds the total)
-__device__ inline double wave_incl_scan(double v) {
-    v += dpp_mov<kShr1, 0xf, true>(v);
-    v += dpp_mov<kShr2, 0xf, true>(v);
-    v += dpp_mov<kShr4, 0xf, true>(v);
-    v += dpp_mov<kShr8, 0xf, true>(v);
-    v += dpp_mov<kBc15, 0xa, true>(v);
-    v += dpp_mov<kBc31, 0xc, true>(v);
-    return v;
-}
-__device__ inline double wave_sum(double v) { return rl(wave_incl_scan(v), 63); }
-__device__ inline double wave_max(double v) {
-    v = fmax(v, dpp_mov<kShr1, 0xf, false>(v));
-    v = fmax(v, dpp_mov<kShr2, 0xf, false>(v));
-    v = fmax(v, dpp_mov<kShr4, 0xf, false>(v));
-    v = fmax(v, dpp_mov<kShr8, 0xf, false>(v));
-    v = fmax(v, dpp_mov<kBc15, 0xa, false>(v));
-    v = fmax(v, dpp_mov<kBc31, 0xc, false>(v));
-    return rl(v, 63);
-}
-__device__ inline double wave_min(double v) { return -wave_max(-v); }
-__device__ inline int wave_min_i(int v) {
-    int t;
-    t = dpp_mov_i<kShr1, 0xf>(v); v = t < v ? t : v;
-    t = dpp_mov_i<kShr2, 0xf>(v); v = t < v ? t : v;
-    t = dpp_mov_i<kShr4, 0xf>(v); v = t < v ? t : v;
-    t = dpp_mov_i<kShr8, 0xf>(v); v = t < v ? t : v;
-    t = dpp_mov_i<kBc15, 0xa>(v); v = t < v ? t : v;
-    t = dpp_mov_i<kBc31, 0xc>(v); v = t < v ? t : v;
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// acc += a * b on the lanes of `mask` only (wave-uniform mask).  One VALU instruction: the mask goes through EXEC on the
-// scalar unit instead of a v_cmp + two v_cndmask per fp64 value.  EXEC is saved and restored inside the statement, so the
-// compiler never sees it changed.
-#ifndef PNX_NNLS_ASM_MASK
-#define PNX_NNLS_ASM_MASK 1
-#endif
-__device__ inline void fma_on(double &acc, double a, double b, unsigned long long mask) {
-#if PNX_NNLS_ASM_MASK
-    unsigned long long keep;
-    asm volatile("s_and_saveexec_b64 %1, %4\n\tv_fma_f64 %0, %2, %3, %0\n\ts_mov_b64 exec, %1"
-                 : "+v"(acc), "=&s"(keep)
-                 : "v"(a), "v"(b), "s"(mask)
-                 : "scc");
-#else
-    if (__builtin_amdgcn_inverse_ballot_w64(mask)) acc = fma(a, b, acc);
-#endif
-}
-// 1 / sqrt(a) for a wave-uniform a > 0: v_rsq_f64 (~2^-26) + two Newton steps instead of the IEEE sqrt + divide
-// expansions (~60 VALU instructions per candidate column)
-__device__ inline double rsqrt_nr(double a) {
-    double y = __builtin_amdgcn_rsq(a);
-    const double h = 0.5 * a;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
-
-__device__ inline void wave_sync() {
-    // one wave per workgroup: "everything I wrote (LDS / my global scratch slab) is visible to my other lanes" is a wait
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1}: one row of G or B is two 16-byte loads per lane.
-__device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
-
-// ---- position-indexed register vectors (position i lives in lane i & 63, slot i >> 6) --------------
-template <int S> struct SlotTag { static constexpr int value = S; };
-// f(i, SlotTag<S>) for every position i in [lo, hi), slot known at compile time
-template <int S, int UNROLL, class F> __device__ inline void pos_range(int lo, int hi, F &&f) {
-    const int a = lo > kW * S ? lo : kW * S;
-    const int b = hi < kW * S + kW ? hi : kW * S + kW;
-#pragma unroll UNROLL
-    for (int i = a; i < b; ++i) f(i, SlotTag<S>{});
-}
-template <int UNROLL, class F> __device__ inline void for_pos(int lo, int hi, F &&f) {
-    pos_range<0, UNROLL>(lo, hi, f);
-    if (hi > kW) pos_range<1, UNROLL>(lo, hi, f);
-    if (hi > 2 * kW) pos_range<2, UNROLL>(lo, hi, f);
-    if (hi > 3 * kW) pos_range<3, UNROLL>(lo, hi, f);
-}
-// the same in groups of four: f4(i, SlotTag<S>) covers positions i .. i + 3 (all in slot S), f1 the ragged rest.  Loops
-// around v_readlane / DPP are never unrolled by the compiler, so "several rows in flight" has to be spelled out.
-template <int S, class F4, class F1> __device__ inline void pos_range4(int lo, int hi, F4 &&f4, F1 &&f1) {
-    const int a = lo > kW * S ? lo : kW * S;
-    const int b = hi < kW * S + kW ? hi : kW * S + kW;
-    int i = a;
-    for (; i + 4 <= b; i += 4) f4(i, SlotTag<S>{});
-    for (; i < b; ++i) f1(i, SlotTag<S>{});
-}
-template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4 &&f4, F1 &&f1) {
-    pos_range4<0>(lo, hi, f4, f1);
-    if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
-    if (hi > 2 * kW) pos_range4<2>(lo, hi, f4, f1);
-    if (hi > 3 * kW) pos_range4<3>(lo, hi, f4, f1);
-}
-// write v at (uniform) position pos.  Written as per-lane selects on purpose: the obvious "if ((pos >> 6) == s) a[s] = v"
-// chain is folded by the optimiser into ONE store with a run-time index, which demotes the whole array from registers
-// to scratch memory (and every later access to it onto the vector-memory pipe, the busiest unit of this kernel).
-__device__ inline void put(double (&a)[kSlots], int pos, double v, int lane) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
-}
-__device__ inline void put_i(int (&a)[kSlots], int pos, int v, int lane) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
-}
-// position i receives the value of position i + 1 (the last position receives garbage)
-__device__ inline void shift_down(const double (&a)[kSlots], double (&out)[kSlots], int lane) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-        double v = __shfl_down(a[s], 1);
-        const double nxt0 = (s + 1 < kSlots) ? rl(a[s + 1 < kSlots ? s + 1 : s], 0) : 0.0;
-        out[s] = (lane == 63) ? nxt0 : v;
-    }
-}
-__device__ inline void shift_down_i(const int (&a)[kSlots], int (&out)[kSlots], int lane) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-        int v = __shfl_down(a[s], 1);
-        const int nxt0 = (s + 1 < kSlots) ? __builtin_amdgcn_readlane(a[s + 1 < kSlots ? s + 1 : s], 0) : 0;
-        out[s] = (lane == 63) ? nxt0 : v;
-    }
-}
 
 // out[s] (k = lane + 64 s) = sum_{i >= k} va_i * M[i][k]  (and the same with vb when TWO): one sweep over the
 // packed lower-triangular M, every row read contiguously; va_i / vb_i are broadcast with v_readlane.
@@ -286,67 +138,6 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
     for_pos4(kLdsRows, p, four, one);
 }
 
-// Lanes of one wave talk through LDS without barriers (the hardware executes a wave's LDS instructions in order).  The
-// COMPILER, however, reasons per thread: "I store xbuf[lane] and later load xbuf[lane + 1]: no alias, the load may move
-// up".  lds_order() is a compiler-only fence (no instruction) that pins the program order of memory operations.
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-
-// t = R v and u = R^T t through the bin-ordered scratch (zero boundary: R is n x n, R[i][j] = c[j - i + 2]);
-// v by position (x, pidx, p).  Returns u by bin in `u`, and sum t^2 of this lane's bins in *tt.  A lane owns the bin
-// pairs (2 l, 2 l + 1) and (128 + 2 l, 129 + 2 l): three 16-byte reads per pair bring the pair and its two neighbours
-// on either side.
-template <bool REV> __device__ __forceinline__ void band5(const double *q, const double (&c)[5], int hb, double &o0, double &o1) {
-    // q points at the pair; taps d = -2 .. 2 of out_j = sum_d c[d + 2] v[j + d]  (REV: c[2 - d], the transposed band)
-    const double2 lo = *reinterpret_cast<const double2 *>(q - 2), mid = *reinterpret_cast<const double2 *>(q),
-                  hi = *reinterpret_cast<const double2 *>(q + 2);
-    const double cm1 = REV ? c[3] : c[1], cp1 = REV ? c[1] : c[3], cm2 = REV ? c[4] : c[0], cp2 = REV ? c[0] : c[4];
-    double a = cm1 * lo.y, b = cm1 * mid.x;
-    a = fma(c[2], mid.x, a);
-    b = fma(c[2], mid.y, b);
-    a = fma(cp1, mid.y, a);
-    b = fma(cp1, hi.x, b);
-    if (hb > 1) {
-        a = fma(cm2, lo.x, a);
-        b = fma(cm2, lo.y, b);
-        a = fma(cp2, hi.x, a);
-        b = fma(cp2, hi.y, b);
-    }
-    o0 = a;
-    o1 = b;
-}
-template <bool WANT_U>
-__device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[kSlots],
-                                 const int (&pidx)[kSlots], double (&u)[kSlots], double *tt) {
-    // bin b lives at xbuf[2 + b]; two zero doubles in front of bin 0 and behind bin 255
-    const double2 zero2 = {0.0, 0.0};
-    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
-    *reinterpret_cast<double2 *>(lo) = zero2;
-    *reinterpret_cast<double2 *>(hi) = zero2;
-    if (lane < 2) *reinterpret_cast<double2 *>(xbuf + 258 * lane) = zero2;
-    lds_order();
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s)
-        if (lane + kW * s < p) xbuf[2 + pidx[s]] = x[s];
-    lds_order();
-    double t[kSlots];
-    band5<false>(lo, c, hb, t[0], t[1]);
-    band5<false>(hi, c, hb, t[2], t[3]);
-    double acc = 0;
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-        t[s] = (binof(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
-        acc = fma(t[s], t[s], acc);
-    }
-    if (tt) *tt = acc;
-    lds_order();
-    if (!WANT_U) return;
-    *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
-    *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
-    lds_order();
-    band5<true>(lo, c, hb, u[0], u[1]);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
-    band5<true>(hi, c, hb, u[2], u[3]);
-    lds_order();
-}
 
 #ifdef PNX_NNLS_STAMP
 #define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
@@ -1030,6 +821,11 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     hipLaunchKernelGGL(gram_kernel, dim3((n_bins + 63) / 64, n_bins), dim3(64), 0, 0, P->B, P->RT, n_meas, n_bins,
                        n_reg, P->G);
     PNX_HIPN(hipGetLastError());
+    if (!P->qr && nnls_blk_applicable(P)) {
+        P->blk = true;
+        const int rc_ = nnls_blk_plan_init(P);
+        if (rc_ != PNX_OK) return rc_;
+    }
     // persistent grid: as many single-wave workgroups as fit (LDS bound), one scratch slab each
     PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
     int occ = 0;
@@ -1052,6 +848,7 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->RT) (void)hipFree(P->RT);
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
+    if (P->Mblk) (void)hipFree(P->Mblk);
     if (P->aty) (void)hipFree(P->aty);
     if (P->queue) (void)hipFree(P->queue);
     *P = NnlsPlanData();
@@ -1062,6 +859,7 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
     // Voxels go through in chunks of kAtyChunk: the MFMA Gram step fills ATY for the chunk, the persistent
     // active-set kernel consumes it (256 voxels per resident wave at full occupancy keep the drain tail small; 2 GiB of ATY scratch).
     if (P->qr) return nnls_qr_solve_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, stream);
+    if (P->blk) return nnls_blk_solve_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, stream);
     const bool use_mfma = P->aty != nullptr;
     for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
         const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;

@@ -25,6 +25,9 @@ struct NnlsPlanData {
     double rc[5] = {0, 0, 0, 0, 0};  // banded Toeplitz regulariser (orders 1-3 of the reference): reg[i][j] = rc[j - i + 2]
     int rhb = 0;              // its half bandwidth, 0 = general regulariser
     bool qr = false;          // no (or an all-zero) regulariser and <= 64 measurements: QR-based kernel (pnx_nnls_qr.hip)
+    bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
+    double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
+    int blk_groups = 0;       // its persistent workgroups (16 waves each)
     unsigned long long *queue = nullptr;
 };
 
@@ -35,6 +38,10 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream);
 int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                          int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+bool nnls_blk_applicable(const NnlsPlanData *P);
+int nnls_blk_plan_init(NnlsPlanData *P);
+int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                          int8_t *status_d, int32_t *iters_d, hipStream_t stream);
 int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream);
 int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis);
 

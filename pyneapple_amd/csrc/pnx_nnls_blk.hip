@@ -1,0 +1,837 @@
+// pnx_nnls_blk.hip -- Lawson-Hanson NNLS for the reference's banded Tikhonov regularisers, second formulation (fp64).
+//
+// Hot path replaced: NNLSSolver._fit_single_pixel -> scipy.optimize.nnls(A, y_ext, maxiter) per voxel
+// (reference src/pyneapple/solvers/nnls_solver.py:129-210) with A = [basis; mu * R] (nnls_solver.py:61-73) and R one of
+// the banded Toeplitz matrices of model_functions/nnls.py:46-85.  Same active-set path as pnx_nnls.hip (selection rule,
+// 0.01 independence test, alpha step, clean-up loop, `iteration == maxiter`), so iteration counts stay those of SciPy.
+//
+// Why a second kernel.  pnx_nnls.hip keeps every unit of a CU 55-70 % busy at once: the vector L1 (the dual
+// w = A^T y - G[:,P] x streams p rows of G = 2 KB each per outer iteration: 87 k L1 accesses per voxel), the VALU and the
+// scalar unit (one dependent LDS round trip and ~8 instructions per row of the inverse factor M, four sweeps over M per
+// iteration).  This kernel removes both loads:
+//   * THE BASIS LIVES IN LDS, ONCE PER CU (32 x 258 doubles = 66 KB, shared by the 16 waves of the only workgroup a CU
+//     holds).  The dual is evaluated in residual form, w = B^T (y - B_P x_P) - R^T (R x): p column gathers and 32 row
+//     reads out of LDS plus two 5-point stencils -- no row of G is read at all (G is only gathered: p numbers per
+//     candidate column), and the cancellation-free residual form is the more accurate one.  A^T y is never formed, so
+//     the MFMA Gram step and its 2 KB per voxel round trip through HBM are not part of this path.
+//   * M = L^-1 IS DISTRIBUTED IN 8 x 8 BLOCKS OVER THE WAVE.  Lane (a, b) = (lane >> 3, lane & 7) owns element
+//     (8 I + a, 8 K + b) of block (I, K).  A product with M or M^T is then one FMA per block and lane (21 for 48 rows)
+//     and a three-step butterfly per block row / column (DPP within 16 lanes, v_permlane16/32_swap across), with all
+//     block loads in flight together -- instead of p dependent row steps.  M lives in a per-wave global slab (L2), rows
+//     padded to multiples of 8 so that block reads are whole 64-byte lines and row accesses stay contiguous; both
+//     sweeps of an append (l = M g, then l^T M) use the same register copy of the blocks.  Rows >= 48 (and the Givens
+//     sweep of a removal) go through the slab row by row with the loads of four rows in flight.
+// One wavefront owns one voxel; waves pull voxels from an atomic queue and never meet after the basis is staged.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "pnx_internal.hpp"
+#include "pnx_nnls.hpp"
+#include "pnx_nnls_dev.hpp"
+
+namespace pnx {
+
+constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
+constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
+constexpr int kBlkWaves = 16;               // waves per workgroup = voxels in flight per CU
+constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
+constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
+// per-wave LDS scratch, in doubles: xs[256] x by position | ps[256] (ints) bin by position | xbuf[264] x by bin with halo
+// (also the staging buffer of the M sweeps) | rb[32] residual of the measurements
+constexpr int kScr = 256 + 128 + kXbuf + 32;
+constexpr int kMSlab = 32 * 32 * 33;  // doubles of M per wave: moff(256)
+typedef int __attribute__((may_alias)) lds_int;
+
+struct BlkArgs {
+    const double *y;
+    double *coeff;
+    double *rnorm;
+    int8_t *status;
+    int32_t *iters;
+    const double *G;   // (n_bins, 256) zero padded
+    const double *Bp;  // (n_meas, 256) zero padded
+    double *Mglob;     // kMSlab doubles per wave, zero initialised (so that every block a sweep touches is finite)
+    unsigned long long *queue;
+    long long n_vox;
+    int n_meas, n_bins, n_reg, max_iter;
+    double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] (mu included)
+    int rhb;       // half bandwidth, 1 or 2
+};
+
+// -DPNX_NNLS_BLK_CHECK: every index into the slab of M / a row of G is range checked; the first violation is reported with
+// printf and the access is redirected to element 0 (diagnostic builds only)
+#ifdef PNX_NNLS_BLK_CHECK
+__device__ int g_blk_err = 0;
+__device__ __noinline__ int ck_(int idx, int lim, int code, int aux) {
+    if (idx < 0 || idx >= lim) {
+        if (atomicAdd(&g_blk_err, 1) == 0) printf("BLK_CHECK code=%d idx=%d lim=%d aux=%d block=%d thread=%d\n", code, idx, lim, aux, (int)blockIdx.x, (int)threadIdx.x);
+        return 0;
+    }
+    return idx;
+}
+#define CK(idx, lim, code, aux) ck_((idx), (lim), (code), (aux))
+#else
+#define CK(idx, lim, code, aux) (idx)
+#endif
+
+// Row i of M starts at moff(i): rows are padded to a multiple of 8 entries, so block row I (rows 8 I .. 8 I + 7) has
+// I + 1 blocks of 8 x 8 and each lane row of a block is one 64-byte line.
+__device__ __forceinline__ int moff(int i) {
+    const int I = i >> 3, a = i & 7;
+    return (I + 1) * (32 * I + 8 * a);
+}
+
+// ---- reductions over one axis of the 8 x 8 lane grid (every lane of the group gets the sum) ----------------
+template <int CTRL> __device__ __forceinline__ double dppx(double v) { return dpp_mov<CTRL, 0xf, false>(v); }
+__device__ __forceinline__ double swap_add16(double v) {  // + the lane 16 away (rows of 16 lanes swapped pairwise)
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double swap_add32(double v) {  // + the lane 32 away
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// a value every lane holds, moved to scalar registers: the branches that depend on it become scalar branches (a per-lane
+// condition around DPP / readlane / permlane code makes the compiler mask a loop that no lane ever leaves alone)
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// over b = lane & 7: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+__device__ __forceinline__ double allreduce_b(double v) {
+    v += dppx<0xB1>(v);
+    v += dppx<0x4E>(v);
+    v += dppx<0x141>(v);
+    return v;
+}
+// over a = lane >> 3: row_ror 8, then the two swaps
+__device__ __forceinline__ double allreduce_a(double v) {
+    v += dppx<0x128>(v);
+    v = swap_add16(v);
+    v = swap_add32(v);
+    return v;
+}
+
+// ---- products with the LDS-resident basis ------------------------------------------------------------------
+// stage x / pidx by position (zeros behind position p up to the end of its slot)
+__device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kSlots],
+                                                const int (&pidx)[kSlots]) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int i = lane + kW * s;
+        if (kW * s <= p) {  // wave uniform
+            xs[i] = i < p ? x[s] : 0.0;
+            ps[i] = i < p ? pidx[s] : 0;
+        }
+    }
+}
+// every lane: (B_P x_P)[m], m = lane & 31.  Half wave h takes the positions h, h + 2, ...
+__device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs, const lds_int *ps, int p, int lane) {
+    const int m = lane & 31, h = lane >> 5;
+    const double *Bm = Bl + m * kBStride;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int p2 = (p + 1) & ~1;  // rounded up to a pair: the pad entry holds x = 0, bin 0
+    int i = h;
+    for (; i + 6 < p2; i += 8) {
+        const double x0 = xs[i], x1 = xs[i + 2], x2 = xs[i + 4], x3 = xs[i + 6];
+        const int j0 = ps[i], j1 = ps[i + 2], j2 = ps[i + 4], j3 = ps[i + 6];
+        a0 = fma(x0, Bm[j0], a0);
+        a1 = fma(x1, Bm[j1], a1);
+        a2 = fma(x2, Bm[j2], a2);
+        a3 = fma(x3, Bm[j3], a3);
+    }
+    for (; i < p2; i += 2) a0 = fma(xs[i], Bm[ps[i]], a0);
+    return swap_add32((a0 + a1) + (a2 + a3));
+}
+// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS
+__device__ __forceinline__ void bt_times(const double *Bl, const double *v, int lane, double (&out)[kSlots]) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) out[s] = 0;
+#pragma unroll 1
+    for (int m = 0; m < kBMeas; m += 4) {
+        const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
+        const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
+        const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double *row = Bl + (m + r) * kBStride + 2 * lane;
+            const double2 b0 = *reinterpret_cast<const double2 *>(row);
+            const double2 b1 = *reinterpret_cast<const double2 *>(row + 128);
+            out[0] = fma(b0.x, vv[r], out[0]);
+            out[1] = fma(b0.y, vv[r], out[1]);
+            out[2] = fma(b1.x, vv[r], out[2]);
+            out[3] = fma(b1.y, vv[r], out[3]);
+        }
+    }
+}
+
+#ifdef PNX_NNLS_STAMP
+#define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
+// The queue pull sits in a function of its own: inlined, its one-lane branch is merged by the compiler into the control flow
+// of the voxel loop, which then runs under EXEC masks it derives per lane -- around DPP / readlane / permlane code.
+__device__ __noinline__ unsigned long long next_voxel(unsigned long long *queue, int lane) {
+    unsigned long long vq = 0;
+    if (lane == 0) vq = atomicAdd(queue, 1ULL);
+    return vq;
+}
+
+// per-voxel state that the phases below share
+struct VoxState {
+    double q[kSlots], x[kSlots], z[kSlots];
+    int pidx[kSlots];
+    bool inP[kSlots];
+    int p;
+};
+
+// blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
+template <int NI> __device__ __forceinline__ void load_blocks(const double *Mg, int la, int lb, double (&blk)[NI][NI]) {
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+        const int base = (I + 1) * (32 * I + 8 * la) + lb;
+#pragma unroll
+        for (int K = 0; K <= I; ++K) blk[I][K] = Mg[CK(base + 8 * K, kMSlab, 1, I)];
+    }
+}
+
+// Column jmax wants to enter.  l = M g (g = G[P, jmax]), lam^2 = G_jj - |l|^2, Lawson-Hanson independence test; when it
+// passes: new row of M = [-(l^T M) / lam, 1 / lam], z = x + row * qn (x == M^T q whenever a column enters), q_p = qn.
+// Returns false when the column is rejected (nothing changed).
+template <int NI>
+__device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const double *xs, const lds_int *ps, int lane, int la,
+                                           int lb, int jmax, double wj, VoxState &S) {
+    const int p = __builtin_amdgcn_readfirstlane(S.p);
+    const int p2d = p < kRows2D ? p : kRows2D;
+    const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
+    double blk[NI][NI];
+    load_blocks<NI>(Mg, la, lb, blk);
+    const double Gjj = uni(grow[CK(jmax, kNnlsMaxBins, 2, p)]);
+    // g in column layout: lane (a, b) holds g_{8 K + b}
+    double gc[NI];
+#pragma unroll
+    for (int K = 0; K < NI; ++K) {
+        const int k = 8 * K + lb;
+        const bool ok = k < p2d;
+        const int j = ok ? ps[k] : 0;
+        const double gv = grow[CK(j, kNnlsMaxBins, 3, k)];
+        gc[K] = ok ? gv : 0.0;
+    }
+    // l in row layout: lane (a, b) holds l_{8 I + a}
+    double lr[NI];
+    double ll = 0;
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+        double acc = 0;
+#pragma unroll
+        for (int K = 0; K <= I; ++K) acc = fma(blk[I][K], gc[K], acc);
+        acc = allreduce_b(acc);
+        lr[I] = (8 * I + la < p2d) ? acc : 0.0;
+        ll = fma(lr[I], lr[I], ll);
+    }
+    ll = uni(allreduce_a(ll));
+    // rows >= 48: row by row (lanes over the columns), four rows in flight
+    double lcan[kSlots] = {0, 0, 0, 0};  // l by position, rows >= 48 only
+    double g[kSlots] = {0, 0, 0, 0};
+    if (p > kRows2D) {
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
+        auto one = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            const int rbase = moff(i);
+            double part = 0;
+#pragma unroll
+            for (int s = 0; s <= si; ++s) {
+                const int k = lane + kW * s;
+                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];  // past the row end: the following rows of this wave's slab (masked below)
+                part += (k <= i) ? m0 * g[s] : 0.0;
+            }
+            const double li = wave_sum(part);
+            if (lane == (i & 63)) lcan[si] = li;
+            ll = fma(li, li, ll);
+        };
+        auto four = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            double m[4][si + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rbase = moff(i + r);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
+            }
+            double part[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part[r] = 0;
+#pragma unroll
+                for (int s = 0; s <= si; ++s) part[r] += (lane + kW * s <= i + r) ? m[r][s] * g[s] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double li = wave_sum(part[r]);
+                if (lane == ((i + r) & 63)) lcan[si] = li;
+                ll = fma(li, li, ll);
+            }
+        };
+        for_pos4(kRows2D, p, four, one);
+    }
+    // wave-uniform scalar algebra on v_rsq_f64 + Newton (pnx_nnls.hip)
+    const double lam2 = Gjj - ll;
+    const bool indep = lam2 > 64.0 * 2.220446049250313e-16 * Gjj;
+    const double ilam = indep ? rsqrt_nr(lam2) : 0.0;
+    double lam = lam2 * ilam;
+    lam = fma(0.5 * ilam, fma(-lam, lam, lam2), lam);  // sqrt(lam2) to within an ulp
+    const double un = ll > 0 ? ll * rsqrt_nr(ll) : 0.0;
+    bool ok = ((un + lam * 0.01) - un) > 0;  // Lawson-Hanson linear-independence test
+    // ztest = qn / lam with qn = (a_j^T residual) / lam: the residual-form dual w_j IS a_j^T residual
+    const double qn = wj * ilam;
+    ok = ok && qn > 0;
+    if (!ok) return false;
+#ifdef PNX_NNLS_TRACE
+    if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) printf("A p=%d j=%d lam=%.17g qn=%.17g\n", p, jmax, lam, qn);
+#endif
+    // a1 = l^T M by position
+    double rK[NI];
+#pragma unroll
+    for (int K = 0; K < NI; ++K) {
+        double acc = 0;
+#pragma unroll
+        for (int I = K; I < NI; ++I) acc = fma(blk[I][K], lr[I], acc);
+        rK[K] = allreduce_a(acc);
+    }
+    double a1[kSlots] = {0, 0, 0, 0};
+#pragma unroll
+    for (int K = 0; K < NI; ++K) a1[0] = (la == K) ? rK[K] : a1[0];  // position 8 la + lb is column (K = la, b = lb)
+    if (p > kRows2D) {
+        auto one = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            const double a = rl(lcan[si], i & 63);
+            const int rbase = moff(i);
+#pragma unroll
+            for (int s = 0; s <= si; ++s) {
+                const int k = lane + kW * s;
+                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];
+                a1[s] += a * ((k <= i) ? m0 : 0.0);
+            }
+        };
+        auto four = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            double m[4][si + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rbase = moff(i + r);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a = rl(lcan[si], (i + r) & 63);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) a1[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
+            }
+        };
+        for_pos4(kRows2D, p, four, one);
+    }
+    // the new row (padded to the block boundary with zeros) and the rank-one update of the solution
+    if (p < kRows2D) {
+        if (la == (p & 7)) {
+            const int pbase = moff(p) + lb;
+#pragma unroll
+            for (int K = 0; K < NI; ++K) {
+                const int k = 8 * K + lb;
+                if (K <= (p >> 3)) Mg[CK(pbase + 8 * K, kMSlab, 7, p)] = k < p ? -rK[K] * ilam : (k == p ? ilam : 0.0);
+            }
+        }
+    } else {
+        const int pbase = moff(p);
+        const int width = 8 * ((p >> 3) + 1);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int k = lane + kW * s;
+            if (k < width) Mg[CK(pbase + k, kMSlab, 8, p)] = k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int k = lane + kW * s;
+        if (k < p) {
+            const double r = -a1[s] * ilam;
+            S.z[s] = S.x[s] + r * qn;
+        } else if (k == p)
+            S.z[s] = qn * ilam;
+        if (binof(lane, s) == jmax) S.inP[s] = true;
+    }
+    put(S.q, p, qn, lane);
+    put(S.x, p, 0.0, lane);
+    put_i(S.pidx, p, jmax, lane);
+    S.p = p + 1;
+    return true;
+}
+
+// z = M^T q
+template <int NI>
+__device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, int la, int lb, VoxState &S) {
+    const int p = __builtin_amdgcn_readfirstlane(S.p);
+    const int p2d = p < kRows2D ? p : kRows2D;
+    double blk[NI][NI];
+    load_blocks<NI>(Mg, la, lb, blk);
+    lds_order();
+    stg[lane] = S.q[0];
+    lds_order();
+    double qr[NI];
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+        const double v = stg[8 * I + la];
+        qr[I] = (8 * I + la < p2d) ? v : 0.0;
+    }
+    lds_order();
+    double z0 = 0;
+#pragma unroll
+    for (int K = 0; K < NI; ++K) {
+        double acc = 0;
+#pragma unroll
+        for (int I = K; I < NI; ++I) acc = fma(blk[I][K], qr[I], acc);
+        acc = allreduce_a(acc);
+        z0 = (la == K) ? acc : z0;
+    }
+    S.z[0] = z0;
+#pragma unroll
+    for (int s = 1; s < kSlots; ++s) S.z[s] = 0;
+    if (p > kRows2D) {
+        auto one = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            const double a = rl(S.q[si], i & 63);
+            const int rbase = moff(i);
+#pragma unroll
+            for (int s = 0; s <= si; ++s) {
+                const int k = lane + kW * s;
+                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];
+                S.z[s] += a * ((k <= i) ? m0 : 0.0);
+            }
+        };
+        auto four = [&](int i, auto T) {
+            constexpr int si = decltype(T)::value;
+            double m[4][si + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rbase = moff(i + r);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a = rl(S.q[si], (i + r) & 63);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) S.z[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
+            }
+        };
+        for_pos4(kRows2D, p, four, one);
+    }
+}
+
+__global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A) {
+#ifdef PNX_NNLS_STAMP
+    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ double dyn_lds[];
+    const int lane = threadIdx.x & (kW - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int la = lane >> 3, lb = lane & 7;
+    const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
+    const int m_total = nm + nreg;
+    double *Bl = dyn_lds;
+    double *scr = dyn_lds + kBMeas * kBStride + wave * kScr;
+    double *xs = scr;                                        // [256] x by position
+    lds_int *ps = reinterpret_cast<lds_int *>(scr + 256);    // [256] bin by position
+    double *xbuf = scr + 256 + 128;                          // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
+    double *rb = xbuf + kXbuf;                               // [32] residual of the measurements
+    double *Mg = A.Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
+    for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
+        const int m = e / kBStride, j = e - m * kBStride;
+        Bl[e] = (m < nm && j < kNnlsMaxBins) ? A.Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
+    }
+    __syncthreads();  // the only workgroup barrier: from here on the waves never meet again
+
+    for (;;) {
+        unsigned long long vq = next_voxel(A.queue, lane);
+        vq = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vq >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
+        if (vq >= (unsigned long long)A.n_vox) break;
+        const long long vox = (long long)vq;
+        const double *yv = A.y + (size_t)vox * nm;
+
+        // y by measurement: lanes 0 .. 31, duplicated in 32 .. 63
+        const int ml = lane & 31;
+        const double yreg = ml < nm ? yv[ml] : 0.0;
+        const bool finite = __all(isfinite(yreg) ? 1 : 0) != 0;
+        const double yn2 = wave_sum(lane < kBMeas ? yreg * yreg : 0.0);
+        VoxState S;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            S.q[s] = 0;
+            S.x[s] = 0;
+            S.z[s] = 0;
+            S.pidx[s] = 0;
+            S.inP[s] = false;
+        }
+        S.p = 0;
+        int iteration = 0, status = finite ? 1 : -2;
+        double w[kSlots];
+        STAMP(0);
+
+        while (status == 1 && S.p < n && S.p < m_total) {
+            // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
+            lds_order();
+            stage_positions(xs, ps, S.p, lane, S.x, S.pidx);
+            lds_order();
+            const double bx = b_times_xp(Bl, xs, ps, S.p, lane);
+            if (lane < kBMeas) rb[lane] = yreg - bx;
+            lds_order();
+            bt_times(Bl, rb, lane, w);
+            lds_order();
+            {
+                double u[kSlots];
+                reg_terms<true>(xbuf, A.rc, A.rhb, n, S.p, lane, S.x, S.pidx, u, nullptr);
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) w[s] -= u[s];
+            }
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if (S.inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
+            STAMP(1);
+
+            bool accepted = false;
+            for (;;) {
+                // ---- largest positive w_j (ties: lowest bin)
+                double best = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) best = fmax(best, w[s]);
+                best = wave_max(best);
+                if (!(best > 0)) break;  // KKT satisfied
+                int bj = kNone;
+#pragma unroll
+                for (int s = kSlots - 1; s >= 0; --s)
+                    if (w[s] == best) bj = binof(lane, s);
+                const int jmax = wave_min_i(bj);
+                if (jmax == kNone) break;  // cannot happen (some lane holds the maximum); never index G with it
+                const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
+                if (nI <= 2)
+                    accepted = try_append<2>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                else if (nI <= 4)
+                    accepted = try_append<4>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                else
+                    accepted = try_append<6>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                if (accepted) break;
+                // reject: w[j] = 0 and look for the next largest
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (binof(lane, s) == jmax) w[s] = 0.0;
+            }
+            STAMP(2);
+            if (!accepted) break;
+            wave_sync();
+            STAMP(3);
+
+            // ---- inner loop: keep the passive-set solution feasible
+            for (;;) {
+                iteration += 1;
+                if (iteration == A.max_iter) {
+                    status = 0;
+                    break;
+                }
+                const int p = __builtin_amdgcn_readfirstlane(S.p);
+                {
+                    bool viol = false;
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) viol = viol || (lane + kW * s < p && S.z[s] <= 0);
+                    if (!__any(viol ? 1 : 0)) {
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s)
+                            if (lane + kW * s < p) S.x[s] = S.z[s];
+                        break;
+                    }
+                }
+                double bestT = INFINITY;
+                int bpos = kNone;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) {
+                    const int i = lane + kW * s;
+                    if (i < p && S.z[s] <= 0) {
+                        const double T = -S.x[s] / (S.z[s] - S.x[s]);
+                        if (T < bestT) {
+                            bestT = T;
+                            bpos = i;
+                        }
+                    }
+                }
+                {
+                    const double gmin = wave_min(bestT);
+                    bpos = (bestT == gmin && bpos != kNone) ? bpos : kNone;
+                    bpos = wave_min_i(bpos);  // ties: first position (Lawson-Hanson keeps the first minimum)
+                    bestT = gmin;
+                }
+                if (bpos == kNone) {
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s)
+                        if (lane + kW * s < p) S.x[s] = S.z[s];
+                    break;
+                }
+                const double alpha = bestT;
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (lane + kW * s < p) S.x[s] = S.x[s] + alpha * (S.z[s] - S.x[s]);
+                STAMP(4);
+                int jj = bpos;
+                for (;;) {
+                    jj = __builtin_amdgcn_readfirstlane(jj);
+                    const int pp = __builtin_amdgcn_readfirstlane(S.p);
+                    // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
+                    // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
+                    double mv[kSlots], pre[kSlots];
+                    double carry = 0;
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) {
+                        const int i = lane + kW * s;
+                        mv[s] = 0;
+                        pre[s] = carry;
+                        if (kW * s < pp) {
+                            if (i >= jj && i < pp) mv[s] = Mg[CK(moff(i) + jj, kMSlab, 9, i)];
+                            const double sc = wave_incl_scan(mv[s] * mv[s]);
+                            pre[s] = sc + carry;
+                            carry += rl(sc, 63);
+                        }
+                    }
+                    double mnext[kSlots], prenext[kSlots];
+                    shift_down(mv, mnext, lane);
+                    shift_down(pre, prenext, lane);
+                    double cs[kSlots], sn[kSlots];
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) {
+                        const int i = lane + kW * s;
+                        cs[s] = 1.0;
+                        sn[s] = 0.0;
+                        if (i >= jj && i < pp - 1) {
+                            const double a = (i == jj) ? mv[s] : sqrt(pre[s]);  // first carried value keeps its sign
+                            const double b = mnext[s];
+                            const double r = sqrt(prenext[s]);
+                            if (r > 0) {
+                                cs[s] = b / r;
+                                sn[s] = a / r;
+                            }
+                        }
+                    }
+                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
+                                      : jj < 2 * kW ? __builtin_amdgcn_readlane(S.pidx[1], jj & 63)
+                                      : jj < 3 * kW ? __builtin_amdgcn_readlane(S.pidx[2], jj & 63)
+                                                    : __builtin_amdgcn_readlane(S.pidx[3], jj & 63);
+                    {
+                        double car[kSlots];
+                        const int jbase = moff(jj);
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s) {
+                            const int c = lane + kW * s;
+                            car[s] = (c < jj) ? Mg[CK(jbase + c, kMSlab, 10, jj)] : 0.0;
+                        }
+                        double carq = jj < kW ? rl(S.q[0], jj & 63) : jj < 2 * kW ? rl(S.q[1], jj & 63)
+                                    : jj < 3 * kW ? rl(S.q[2], jj & 63) : rl(S.q[3], jj & 63);
+                        double qsh[kSlots];
+                        shift_down(S.q, qsh, lane);  // qsh[i] = q[i + 1]
+                        // row i of the new factor from the carried combination and old row i + 1 (column jj dropped);
+                        // the loads of four rows are in flight before the first rotation
+                        auto one = [&](int i, auto T) {
+                            constexpr int si = decltype(T)::value;
+                            const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
+                            const double qnx = rl(qsh[si], i & 63);
+                            const int nbase = moff(i + 1), obase = moff(i);
+#pragma unroll
+                            for (int s = 0; s <= si; ++s) {
+                                const int c = lane + kW * s;
+                                const double nxt = Mg[CK(nbase + (c < jj ? c : c + 1), kMSlab, 11, i)];
+                                if (c <= i) {
+                                    const double outv = c_ * car[s] - s_ * nxt;
+                                    car[s] = s_ * car[s] + c_ * nxt;
+                                    Mg[CK(obase + c, kMSlab, 12, i)] = outv;
+                                }
+                            }
+                            const double oq = c_ * carq - s_ * qnx;
+                            carq = s_ * carq + c_ * qnx;
+                            if (lane == (i & 63)) S.q[si] = oq;
+                        };
+                        auto four = [&](int i, auto T) {
+                            constexpr int si = decltype(T)::value;
+                            double nx[4][si + 1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int nbase = moff(i + r + 1);
+#pragma unroll
+                                for (int s = 0; s <= si; ++s) {
+                                    const int c = lane + kW * s;
+                                    nx[r][s] = Mg[CK(nbase + (c < jj ? c : c + 1), kMSlab, 13, i + r)];
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double c_ = rl(cs[si], (i + r) & 63), s_ = rl(sn[si], (i + r) & 63);
+                                const double qnx = rl(qsh[si], (i + r) & 63);
+                                const int obase = moff(i + r);
+#pragma unroll
+                                for (int s = 0; s <= si; ++s) {
+                                    const int c = lane + kW * s;
+                                    if (c <= i + r) {
+                                        const double outv = c_ * car[s] - s_ * nx[r][s];
+                                        car[s] = s_ * car[s] + c_ * nx[r][s];
+                                        Mg[CK(obase + c, kMSlab, 14, i + r)] = outv;
+                                    }
+                                }
+                                const double oq = c_ * carq - s_ * qnx;
+                                carq = s_ * carq + c_ * qnx;
+                                if (lane == ((i + r) & 63)) S.q[si] = oq;
+                            }
+                        };
+                        for_pos4(jj, pp - 1, four, one);
+                    }
+                    // ---- drop position jj from x / pidx
+                    {
+                        double xsh[kSlots];
+                        int psh[kSlots];
+                        shift_down(S.x, xsh, lane);
+                        shift_down_i(S.pidx, psh, lane);
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s) {
+                            const int i = lane + kW * s;
+                            if (i >= jj && i < pp - 1) {
+                                S.x[s] = xsh[s];
+                                S.pidx[s] = psh[s];
+                            }
+                            if (binof(lane, s) == bin_out) S.inP[s] = false;
+                        }
+                    }
+                    S.p = pp - 1;
+                    wave_sync();
+                    // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
+                    int bad = kNone;
+#pragma unroll
+                    for (int s = kSlots - 1; s >= 0; --s) {
+                        const int i = lane + kW * s;
+                        if (i < S.p && S.x[s] <= 0) bad = i;
+                    }
+                    bad = wave_min_i(bad);
+                    if (bad == kNone) break;
+                    jj = bad;
+                }
+                STAMP(5);
+                // ---- z = M^T q
+                {
+                    const int nI = (S.p + 7) >> 3;
+                    if (nI <= 2)
+                        mt_times_q<2>(Mg, xbuf, lane, la, lb, S);
+                    else if (nI <= 4)
+                        mt_times_q<4>(Mg, xbuf, lane, la, lb, S);
+                    else
+                        mt_times_q<6>(Mg, xbuf, lane, la, lb, S);
+                }
+                STAMP(6);
+            }
+        }
+        STAMP(7);
+
+        // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
+        double xb[kSlots] = {0, 0, 0, 0};
+        double rn;
+        if (status == 1) {
+            double tt = 0, dummy[kSlots];
+            lds_order();
+            reg_terms<false>(xbuf, A.rc, A.rhb, n, S.p, lane, S.x, S.pidx, dummy, &tt);  // leaves x in bin order in xbuf
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof(lane, s)];
+            lds_order();
+            stage_positions(xs, ps, S.p, lane, S.x, S.pidx);
+            lds_order();
+            const double bx = b_times_xp(Bl, xs, ps, S.p, lane);
+            lds_order();
+            const double r = lane < kBMeas ? yreg - bx : 0.0;
+            rn = sqrt(wave_sum(fma(r, r, tt)));
+        } else
+            rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
+        double *cv = A.coeff + (size_t)vox * n;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int j = binof(lane, s);
+            if (j < n) cv[j] = xb[s];
+        }
+        if (lane == 0) {
+            A.rnorm[vox] = rn;
+            if (A.status) A.status[vox] = (int8_t)status;
+            if (A.iters) A.iters[vox] = iteration;
+        }
+        STAMP(8);
+    }
+#ifdef PNX_NNLS_STAMP
+    if (threadIdx.x == 0 && blockIdx.x == 7)
+        printf("STAMP setup=%llu dual=%llu cand+append=%llu sync=%llu alpha=%llu removal=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7], seg[8]);
+#endif
+}
+
+#define PNX_HIPB(call)                                                                             \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+static size_t blk_lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * kScr); }
+
+bool nnls_blk_applicable(const NnlsPlanData *P) {
+    return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && getenv("PNX_NNLS_BLK");  // opt-in while it is tuned
+}
+
+// scratch of the block kernel: one workgroup of 16 waves per CU, kMSlab doubles of M per wave (zero initialised: the block
+// sweeps read whole blocks, also rows no voxel of this wave has written yet)
+int nnls_blk_plan_init(NnlsPlanData *P) {
+    PNX_HIPB(hipFuncSetAttribute((const void *)nnls_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes()));
+    int occ = 0;
+    PNX_HIPB(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_blk_kernel, kBlkWaves * kW, blk_lds_bytes()));
+    if (occ < 1) return set_error(PNX_ERR_HIP, "nnls block kernel does not fit on a CU");
+    P->blk_groups = occ * P->cus;
+    const size_t bytes = (size_t)P->blk_groups * kBlkWaves * kMSlab * sizeof(double);
+    PNX_HIPB(hipMalloc(&P->Mblk, bytes));
+    PNX_HIPB(hipMemset(P->Mblk, 0, bytes));
+    return PNX_OK;
+}
+
+int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                          int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
+    if (n_vox <= 0) return PNX_OK;
+    BlkArgs a;
+    a.y = y_d;
+    a.coeff = coeff_d;
+    a.rnorm = rnorm_d;
+    a.status = status_d;
+    a.iters = iters_d;
+    a.G = P->G;
+    a.Bp = P->Bp;
+    a.Mglob = P->Mblk;
+    a.queue = P->queue;
+    a.n_vox = n_vox;
+    a.n_meas = P->n_meas;
+    a.n_bins = P->n_bins;
+    a.n_reg = P->n_reg;
+    a.max_iter = max_iter;
+    for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+    a.rhb = P->rhb;
+    PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
+    long long grid = (n_vox + kBlkWaves - 1) / kBlkWaves;
+    if (grid > P->blk_groups) grid = P->blk_groups;
+    hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
+    PNX_HIPB(hipGetLastError());
+    return PNX_OK;
+}
+
+}  // namespace pnx
