@@ -100,8 +100,24 @@ def _stale(unit, force: bool) -> bool:
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     units = _units()
-    todo = [u for u in units if _stale(u, force)]
     objs = [os.path.join(OBJ, u[0]) for u in units]
+    if _VARIANT:
+        # a variant differs from the product in the flags of a few units: link the product's objects for the others
+        base = os.path.join(CSRC, "_obj")
+        keep = []
+        for i, (obj, src, extra) in enumerate(units):
+            po = os.path.join(base, obj)
+            cmd = " ".join([HIPCC, *CXXFLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", po])
+            try:
+                same = open(po + ".cmd").read() == cmd
+            except OSError:
+                same = False
+            if same and not force:
+                objs[i] = po
+            else:
+                keep.append((obj, src, extra))
+        units = keep
+    todo = [u for u in units if _stale(u, force)]
     if not todo and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(o) for o in objs):
         return LIB
     jobs = jobs or min(max(1, len(todo)), max(1, (os.cpu_count() or 2)))

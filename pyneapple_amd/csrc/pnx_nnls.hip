@@ -66,6 +66,7 @@ struct NnlsArgs {
     int n_meas, n_bins, n_reg, max_iter;
     double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] for |j - i| <= 2 (mu included), zero outside
     int rhb;       // its half bandwidth (1 or 2); 0: general regulariser, rows of RT are used instead
+    const int32_t *redo_list, *redo_count;  // non-null: only the voxels redo_list[0 .. *redo_count) (handed over by pnx_nnls_blk.hip)
 };
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
@@ -162,8 +163,12 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
         if (lane == 0) vq = atomicAdd(A.queue, 1ULL);
         vq = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vq >> 32)) << 32) |
              (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
-        if (vq >= (unsigned long long)A.n_vox) break;
-        const long long vox = (long long)vq;
+        long long vox = (long long)vq;
+        if (A.redo_list) {
+            if (vq >= (unsigned long long)*A.redo_count) break;
+            vox = A.redo_list[vq];
+        } else if (vq >= (unsigned long long)A.n_vox)
+            break;
         const double *yv = A.y + (size_t)vox * nm;
 
         // ---- y (by measurement: lane k & 63, slot k >> 6), A^T y = B^T y (by bin)
@@ -849,6 +854,7 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
     if (P->Mblk) (void)hipFree(P->Mblk);
+    if (P->blk_bail) (void)hipFree(P->blk_bail);
     if (P->aty) (void)hipFree(P->aty);
     if (P->queue) (void)hipFree(P->queue);
     *P = NnlsPlanData();
@@ -882,6 +888,7 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
         a.max_iter = max_iter;
         for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
         a.rhb = P->rhb;
+        a.redo_list = a.redo_count = nullptr;
         if (use_mfma) {
             const int kpad = (P->n_meas + 3) & ~3;
             const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);
@@ -898,6 +905,38 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
         hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
         PNX_HIPN(hipGetLastError());
     }
+    return PNX_OK;
+}
+
+int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                     int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream) {
+    NnlsArgs a;
+    a.y = y_d;
+    a.coeff = coeff_d;
+    a.rnorm = rnorm_d;
+    a.status = status_d;
+    a.iters = iters_d;
+    a.G = P->G;
+    a.Bp = P->Bp;
+    a.RT = P->RT;
+    a.aty = nullptr;
+    a.Mglob = P->Mglob;
+    a.queue = P->queue;
+    a.n_vox = n_vox;
+    a.n_meas = P->n_meas;
+    a.n_bins = P->n_bins;
+    a.n_reg = P->n_reg;
+    a.max_iter = max_iter;
+    for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+    a.rhb = P->rhb;
+    a.redo_list = list;
+    a.redo_count = count;
+    PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
+    // a quarter of the persistent grid: with an empty list a wave costs one queue pull
+    long long grid = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
+    if (grid > n_vox) grid = n_vox;
+    hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+    PNX_HIPN(hipGetLastError());
     return PNX_OK;
 }
 

@@ -28,6 +28,7 @@ struct NnlsPlanData {
     bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
     int blk_groups = 0;       // its persistent workgroups (16 waves each)
+    int32_t *blk_bail = nullptr;  // [0]: number of voxels the block kernel handed to the general one (more than 128 passive bins), [1 ..]: their indices
     unsigned long long *queue = nullptr;
 };
 
@@ -38,6 +39,9 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
                       double *rnorm_d, int8_t *status_d, int32_t *iters_d, hipStream_t stream);
 int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                          int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+// the general kernel on the voxels list[0 .. *count) of a chunk (A^T y on the VALU)
+int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                     int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream);
 bool nnls_blk_applicable(const NnlsPlanData *P);
 int nnls_blk_plan_init(NnlsPlanData *P);
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,

@@ -35,13 +35,18 @@ namespace pnx {
 
 constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
 constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
-constexpr int kBlkWaves = 16;               // waves per workgroup = voxels in flight per CU
+#ifndef PNX_BLK_WAVES
+#define PNX_BLK_WAVES 16
+#endif
+constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU
 constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
+constexpr int kPS = 2;                      // register slots of a position-indexed vector: positions < 128
+constexpr int kMaxPos = kPS * kW;           // a voxel whose passive set wants to grow beyond that is handed to pnx_nnls.hip
 constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
-// per-wave LDS scratch, in doubles: xs[256] x by position | ps[256] (ints) bin by position | xbuf[264] x by bin with halo
+// per-wave LDS scratch, in doubles: xs[128] x by position | ps[128] (ints) bin by position | xbuf[264] x by bin with halo
 // (also the staging buffer of the M sweeps) | rb[32] residual of the measurements
-constexpr int kScr = 256 + 128 + kXbuf + 32;
-constexpr int kMSlab = 32 * 32 * 33;  // doubles of M per wave: moff(256)
+constexpr int kScr = kMaxPos + kMaxPos / 2 + kXbuf + 32;
+constexpr int kMSlab = 32 * 16 * 17 + 64;   // doubles of M per wave: moff(128) = 32 I (I + 1) at I = 16, plus the overrun of a 64-lane row read
 typedef int __attribute__((may_alias)) lds_int;
 
 struct BlkArgs {
@@ -53,6 +58,8 @@ struct BlkArgs {
     const double *G;   // (n_bins, 256) zero padded
     const double *Bp;  // (n_meas, 256) zero padded
     double *Mglob;     // kMSlab doubles per wave, zero initialised (so that every block a sweep touches is finite)
+    int32_t *n_bail;   // number of voxels handed over to the general kernel ...
+    int32_t *bail;     // ... and their indices
     unsigned long long *queue;
     long long n_vox;
     int n_meas, n_bins, n_reg, max_iter;
@@ -78,10 +85,12 @@ __device__ __noinline__ int ck_(int idx, int lim, int code, int aux) {
 
 // Row i of M starts at moff(i): rows are padded to a multiple of 8 entries, so block row I (rows 8 I .. 8 I + 7) has
 // I + 1 blocks of 8 x 8 and each lane row of a block is one 64-byte line.
-__device__ __forceinline__ int moff(int i) {
+__host__ __device__ constexpr int moff(int i) {
     const int I = i >> 3, a = i & 7;
     return (I + 1) * (32 * I + 8 * a);
 }
+
+static_assert(kMSlab >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
 
 // ---- reductions over one axis of the 8 x 8 lane grid (every lane of the group gets the sum) ----------------
 template <int CTRL> __device__ __forceinline__ double dppx(double v) { return dpp_mov<CTRL, 0xf, false>(v); }
@@ -119,53 +128,61 @@ __device__ __forceinline__ double allreduce_a(double v) {
 
 // ---- products with the LDS-resident basis ------------------------------------------------------------------
 // stage x / pidx by position (zeros behind position p up to the end of its slot)
-__device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kSlots],
-                                                const int (&pidx)[kSlots]) {
+__device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kPS],
+                                                const int (&pidx)[kPS]) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < kPS; ++s) {
         const int i = lane + kW * s;
-        if (kW * s <= p) {  // wave uniform
+        if (kW * s <= p && i < kMaxPos) {  // wave uniform
             xs[i] = i < p ? x[s] : 0.0;
             ps[i] = i < p ? pidx[s] : 0;
         }
     }
 }
-// every lane: (B_P x_P)[m], m = lane & 31.  Half wave h takes the positions h, h + 2, ...
+// every lane: (B_P x_P)[m], m = lane & 31.  Half wave h takes the positions h, h + 2, ...; the trip count is the same for
+// both halves (the staged arrays are zero padded), so the loop is a scalar one
 __device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs, const lds_int *ps, int p, int lane) {
     const int m = lane & 31, h = lane >> 5;
     const double *Bm = Bl + m * kBStride;
+    const double *xh = xs + h;
+    const lds_int *ph = ps + h;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const int p2 = (p + 1) & ~1;  // rounded up to a pair: the pad entry holds x = 0, bin 0
-    int i = h;
-    for (; i + 6 < p2; i += 8) {
-        const double x0 = xs[i], x1 = xs[i + 2], x2 = xs[i + 4], x3 = xs[i + 6];
-        const int j0 = ps[i], j1 = ps[i + 2], j2 = ps[i + 4], j3 = ps[i + 6];
+    int i = 0;
+    for (; i + 8 <= p2; i += 8) {
+        const double x0 = xh[i], x1 = xh[i + 2], x2 = xh[i + 4], x3 = xh[i + 6];
+        const int j0 = ph[i], j1 = ph[i + 2], j2 = ph[i + 4], j3 = ph[i + 6];
         a0 = fma(x0, Bm[j0], a0);
         a1 = fma(x1, Bm[j1], a1);
         a2 = fma(x2, Bm[j2], a2);
         a3 = fma(x3, Bm[j3], a3);
     }
-    for (; i < p2; i += 2) a0 = fma(xs[i], Bm[ps[i]], a0);
+    for (; i < p2; i += 2) a0 = fma(xh[i], Bm[ph[i]], a0);
     return swap_add32((a0 + a1) + (a2 + a3));
 }
-// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS
+// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS.  Four rows of B (eight ds_read_b128) are in
+// flight while the previous four are consumed.
 __device__ __forceinline__ void bt_times(const double *Bl, const double *v, int lane, double (&out)[kSlots]) {
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) out[s] = 0;
+    const double *col = Bl + 2 * lane;
 #pragma unroll 1
     for (int m = 0; m < kBMeas; m += 4) {
+        double2 c0[4], c1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c0[r] = *reinterpret_cast<const double2 *>(col + (m + r) * kBStride);
+            c1[r] = *reinterpret_cast<const double2 *>(col + (m + r) * kBStride + 128);
+        }
         const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
         const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
         const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double *row = Bl + (m + r) * kBStride + 2 * lane;
-            const double2 b0 = *reinterpret_cast<const double2 *>(row);
-            const double2 b1 = *reinterpret_cast<const double2 *>(row + 128);
-            out[0] = fma(b0.x, vv[r], out[0]);
-            out[1] = fma(b0.y, vv[r], out[1]);
-            out[2] = fma(b1.x, vv[r], out[2]);
-            out[3] = fma(b1.y, vv[r], out[3]);
+            out[0] = fma(c0[r].x, vv[r], out[0]);
+            out[1] = fma(c0[r].y, vv[r], out[1]);
+            out[2] = fma(c1[r].x, vv[r], out[2]);
+            out[3] = fma(c1[r].y, vv[r], out[3]);
         }
     }
 }
@@ -184,11 +201,19 @@ __device__ __noinline__ unsigned long long next_voxel(unsigned long long *queue,
     return vq;
 }
 
+// A copy of the lane id the optimiser cannot see through: what a phase derives from it (LDS addresses, block offsets, lane
+// masks) is computed where the phase starts instead of once per kernel -- hoisted out of the voxel loop those ~40 values
+// do not fit into 128 registers and come back from scratch memory in every inner loop.
+__device__ __forceinline__ int fresh(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 // per-voxel state that the phases below share
 struct VoxState {
-    double q[kSlots], x[kSlots], z[kSlots];
-    int pidx[kSlots];
-    bool inP[kSlots];
+    double q[kPS], x[kPS], z[kPS];  // by position
+    int pidx[kPS];                  // bin of a position
+    bool inP[kSlots];               // by bin
     int p;
 };
 
@@ -205,9 +230,11 @@ template <int NI> __device__ __forceinline__ void load_blocks(const double *Mg, 
 // Column jmax wants to enter.  l = M g (g = G[P, jmax]), lam^2 = G_jj - |l|^2, Lawson-Hanson independence test; when it
 // passes: new row of M = [-(l^T M) / lam, 1 / lam], z = x + row * qn (x == M^T q whenever a column enters), q_p = qn.
 // Returns false when the column is rejected (nothing changed).
+// One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
+// the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
 template <int NI>
-__device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const double *xs, const lds_int *ps, int lane, int la,
-                                           int lb, int jmax, double wj, VoxState &S) {
+__device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const lds_int *ps, int lane, int la, int lb, int jmax,
+                                           double wj, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const int p2d = p < kRows2D ? p : kRows2D;
     const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
@@ -224,8 +251,9 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const d
         const double gv = grow[CK(j, kNnlsMaxBins, 3, k)];
         gc[K] = ok ? gv : 0.0;
     }
-    // l in row layout: lane (a, b) holds l_{8 I + a}
-    double lr[NI];
+    double rK[NI];  // column sums of l^T M, lane (a, b) holds the partial sum over its rows of column 8 K + b
+#pragma unroll
+    for (int K = 0; K < NI; ++K) rK[K] = 0;
     double ll = 0;
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
@@ -233,29 +261,34 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const d
 #pragma unroll
         for (int K = 0; K <= I; ++K) acc = fma(blk[I][K], gc[K], acc);
         acc = allreduce_b(acc);
-        lr[I] = (8 * I + la < p2d) ? acc : 0.0;
-        ll = fma(lr[I], lr[I], ll);
-    }
-    ll = uni(allreduce_a(ll));
-    // rows >= 48: row by row (lanes over the columns), four rows in flight
-    double lcan[kSlots] = {0, 0, 0, 0};  // l by position, rows >= 48 only
-    double g[kSlots] = {0, 0, 0, 0};
-    if (p > kRows2D) {
+        const double lr = (8 * I + la < p2d) ? acc : 0.0;  // l_{8 I + a}, the same in the lanes (a, *)
+        ll = fma(lr, lr, ll);
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
+        for (int K = 0; K <= I; ++K) rK[K] = fma(blk[I][K], lr, rK[K]);
+    }
+    ll = allreduce_a(ll);
+    // rows >= 48: row by row (lanes over the columns), four rows in flight
+    double lcan[kPS] = {0, 0};  // l by position, rows >= 48 only
+    double a1[kPS] = {0, 0};    // l^T M by position
+    if (NI == 6 && p > kRows2D) {
+        double g[kPS];
+#pragma unroll
+        for (int s = 0; s < kPS; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
         auto one = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             const int rbase = moff(i);
-            double part = 0;
+            double part = 0, m[si + 1];
 #pragma unroll
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
-                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];  // past the row end: the following rows of this wave's slab (masked below)
-                part += (k <= i) ? m0 * g[s] : 0.0;
+                m[s] = (k <= i) ? Mg[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end: masked
+                part = fma(m[s], g[s], part);
             }
             const double li = wave_sum(part);
             if (lane == (i & 63)) lcan[si] = li;
             ll = fma(li, li, ll);
+#pragma unroll
+            for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[s], a1[s]);
         };
         auto four = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
@@ -271,17 +304,23 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const d
             for (int r = 0; r < 4; ++r) {
                 part[r] = 0;
 #pragma unroll
-                for (int s = 0; s <= si; ++s) part[r] += (lane + kW * s <= i + r) ? m[r][s] * g[s] : 0.0;
+                for (int s = 0; s <= si; ++s) {
+                    m[r][s] = (lane + kW * s <= i + r) ? m[r][s] : 0.0;
+                    part[r] = fma(m[r][s], g[s], part[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double li = wave_sum(part[r]);
                 if (lane == ((i + r) & 63)) lcan[si] = li;
                 ll = fma(li, li, ll);
+#pragma unroll
+                for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[r][s], a1[s]);
             }
         };
-        for_pos4(kRows2D, p, four, one);
+        for_pos4n<kPS>(kRows2D, p, four, one);
     }
+    ll = uni(ll);
     // wave-uniform scalar algebra on v_rsq_f64 + Newton (pnx_nnls.hip)
     const double lam2 = Gjj - ll;
     const bool indep = lam2 > 64.0 * 2.220446049250313e-16 * Gjj;
@@ -297,50 +336,16 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const d
 #ifdef PNX_NNLS_TRACE
     if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) printf("A p=%d j=%d lam=%.17g qn=%.17g\n", p, jmax, lam, qn);
 #endif
-    // a1 = l^T M by position
-    double rK[NI];
+    // column sums: over a, then to position order (position 8 la + lb is column K = la, b = lb)
+    double r2d = 0;
 #pragma unroll
     for (int K = 0; K < NI; ++K) {
-        double acc = 0;
-#pragma unroll
-        for (int I = K; I < NI; ++I) acc = fma(blk[I][K], lr[I], acc);
-        rK[K] = allreduce_a(acc);
+        rK[K] = allreduce_a(rK[K]);
+        r2d = (la == K) ? rK[K] : r2d;
     }
-    double a1[kSlots] = {0, 0, 0, 0};
-#pragma unroll
-    for (int K = 0; K < NI; ++K) a1[0] = (la == K) ? rK[K] : a1[0];  // position 8 la + lb is column (K = la, b = lb)
-    if (p > kRows2D) {
-        auto one = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            const double a = rl(lcan[si], i & 63);
-            const int rbase = moff(i);
-#pragma unroll
-            for (int s = 0; s <= si; ++s) {
-                const int k = lane + kW * s;
-                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];
-                a1[s] += a * ((k <= i) ? m0 : 0.0);
-            }
-        };
-        auto four = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            double m[4][si + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rbase = moff(i + r);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double a = rl(lcan[si], (i + r) & 63);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) a1[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
-            }
-        };
-        for_pos4(kRows2D, p, four, one);
-    }
+    a1[0] += r2d;
     // the new row (padded to the block boundary with zeros) and the rank-one update of the solution
-    if (p < kRows2D) {
+    if (NI < 6 || p < kRows2D) {
         if (la == (p & 7)) {
             const int pbase = moff(p) + lb;
 #pragma unroll
@@ -353,21 +358,23 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const d
         const int pbase = moff(p);
         const int width = 8 * ((p >> 3) + 1);
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < kPS; ++s) {
             const int k = lane + kW * s;
             if (k < width) Mg[CK(pbase + k, kMSlab, 8, p)] = k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0);
         }
     }
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < kPS; ++s) {
         const int k = lane + kW * s;
         if (k < p) {
             const double r = -a1[s] * ilam;
             S.z[s] = S.x[s] + r * qn;
         } else if (k == p)
             S.z[s] = qn * ilam;
-        if (binof(lane, s) == jmax) S.inP[s] = true;
     }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s)
+        if (binof(lane, s) == jmax) S.inP[s] = true;
     put(S.q, p, qn, lane);
     put(S.x, p, 0.0, lane);
     put_i(S.pidx, p, jmax, lane);
@@ -403,8 +410,8 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
     }
     S.z[0] = z0;
 #pragma unroll
-    for (int s = 1; s < kSlots; ++s) S.z[s] = 0;
-    if (p > kRows2D) {
+    for (int s = 1; s < kPS; ++s) S.z[s] = 0;
+    if (NI == 6 && p > kRows2D) {
         auto one = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             const double a = rl(S.q[si], i & 63);
@@ -432,9 +439,11 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
                 for (int s = 0; s <= si; ++s) S.z[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
             }
         };
-        for_pos4(kRows2D, p, four, one);
+        for_pos4n<kPS>(kRows2D, p, four, one);
     }
 }
+
+constexpr int kBail = 2;  // internal status: the passive set wants more than kMaxPos columns, the general kernel redoes the voxel
 
 __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A) {
 #ifdef PNX_NNLS_STAMP
@@ -444,15 +453,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
     extern __shared__ double dyn_lds[];
     const int lane = threadIdx.x & (kW - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int la = lane >> 3, lb = lane & 7;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
     const int m_total = nm + nreg;
     double *Bl = dyn_lds;
     double *scr = dyn_lds + kBMeas * kBStride + wave * kScr;
-    double *xs = scr;                                        // [256] x by position
-    lds_int *ps = reinterpret_cast<lds_int *>(scr + 256);    // [256] bin by position
-    double *xbuf = scr + 256 + 128;                          // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
-    double *rb = xbuf + kXbuf;                               // [32] residual of the measurements
+    double *xs = scr;                                                  // [128] x by position
+    lds_int *ps = reinterpret_cast<lds_int *>(scr + kMaxPos);          // [128] bin by position
+    double *xbuf = scr + kMaxPos + kMaxPos / 2;                        // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
+    double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
     double *Mg = A.Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
     for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
         const int m = e / kBStride, j = e - m * kBStride;
@@ -475,13 +483,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
         const double yn2 = wave_sum(lane < kBMeas ? yreg * yreg : 0.0);
         VoxState S;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < kPS; ++s) {
             S.q[s] = 0;
             S.x[s] = 0;
             S.z[s] = 0;
             S.pidx[s] = 0;
-            S.inP[s] = false;
         }
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) S.inP[s] = false;
         S.p = 0;
         int iteration = 0, status = finite ? 1 : -2;
         double w[kSlots];
@@ -489,23 +498,24 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
 
         while (status == 1 && S.p < n && S.p < m_total) {
             // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
-            lds_order();
-            stage_positions(xs, ps, S.p, lane, S.x, S.pidx);
-            lds_order();
-            const double bx = b_times_xp(Bl, xs, ps, S.p, lane);
-            if (lane < kBMeas) rb[lane] = yreg - bx;
-            lds_order();
-            bt_times(Bl, rb, lane, w);
-            lds_order();
             {
+                const int ld = fresh(lane);
+                lds_order();
+                stage_positions(xs, ps, S.p, ld, S.x, S.pidx);
+                lds_order();
+                const double bx = b_times_xp(Bl, xs, ps, S.p, ld);
+                if (ld < kBMeas) rb[ld] = yreg - bx;
+                lds_order();
+                bt_times(Bl, rb, ld, w);
+                lds_order();
                 double u[kSlots];
-                reg_terms<true>(xbuf, A.rc, A.rhb, n, S.p, lane, S.x, S.pidx, u, nullptr);
+                reg_terms<true>(xbuf, A.rc, A.rhb, n, S.p, ld, S.x, S.pidx, u, nullptr);
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) w[s] -= u[s];
+                for (int s = 0; s < kSlots; ++s) {
+                    w[s] -= u[s];
+                    if (S.inP[s] || binof(ld, s) >= n) w[s] = -INFINITY;
+                }
             }
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if (S.inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
             STAMP(1);
 
             bool accepted = false;
@@ -522,13 +532,18 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                     if (w[s] == best) bj = binof(lane, s);
                 const int jmax = wave_min_i(bj);
                 if (jmax == kNone) break;  // cannot happen (some lane holds the maximum); never index G with it
+                if (S.p >= kMaxPos) {      // no room for another column in this kernel's registers
+                    status = kBail;
+                    break;
+                }
                 const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
+                const int lc = fresh(lane);
                 if (nI <= 2)
-                    accepted = try_append<2>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                    accepted = try_append<2>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else if (nI <= 4)
-                    accepted = try_append<4>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                    accepted = try_append<4>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else
-                    accepted = try_append<6>(A, Mg, xs, ps, lane, la, lb, jmax, best, S);
+                    accepted = try_append<6>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 if (accepted) break;
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
@@ -551,10 +566,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 {
                     bool viol = false;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) viol = viol || (lane + kW * s < p && S.z[s] <= 0);
+                    for (int s = 0; s < kPS; ++s) viol = viol || (lane + kW * s < p && S.z[s] <= 0);
                     if (!__any(viol ? 1 : 0)) {
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s)
+                        for (int s = 0; s < kPS; ++s)
                             if (lane + kW * s < p) S.x[s] = S.z[s];
                         break;
                     }
@@ -562,7 +577,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 double bestT = INFINITY;
                 int bpos = kNone;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
+                for (int s = 0; s < kPS; ++s) {
                     const int i = lane + kW * s;
                     if (i < p && S.z[s] <= 0) {
                         const double T = -S.x[s] / (S.z[s] - S.x[s]);
@@ -580,13 +595,13 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 }
                 if (bpos == kNone) {
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s)
+                    for (int s = 0; s < kPS; ++s)
                         if (lane + kW * s < p) S.x[s] = S.z[s];
                     break;
                 }
                 const double alpha = bestT;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < kPS; ++s)
                     if (lane + kW * s < p) S.x[s] = S.x[s] + alpha * (S.z[s] - S.x[s]);
                 STAMP(4);
                 int jj = bpos;
@@ -595,10 +610,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                     const int pp = __builtin_amdgcn_readfirstlane(S.p);
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-                    double mv[kSlots], pre[kSlots];
+                    double mv[kPS], pre[kPS];
                     double carry = 0;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
+                    for (int s = 0; s < kPS; ++s) {
                         const int i = lane + kW * s;
                         mv[s] = 0;
                         pre[s] = carry;
@@ -609,12 +624,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                             carry += rl(sc, 63);
                         }
                     }
-                    double mnext[kSlots], prenext[kSlots];
+                    double mnext[kPS], prenext[kPS];
                     shift_down(mv, mnext, lane);
                     shift_down(pre, prenext, lane);
-                    double cs[kSlots], sn[kSlots];
+                    double cs[kPS], sn[kPS];
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
+                    for (int s = 0; s < kPS; ++s) {
                         const int i = lane + kW * s;
                         cs[s] = 1.0;
                         sn[s] = 0.0;
@@ -629,20 +644,17 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                         }
                     }
                     const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
-                                      : jj < 2 * kW ? __builtin_amdgcn_readlane(S.pidx[1], jj & 63)
-                                      : jj < 3 * kW ? __builtin_amdgcn_readlane(S.pidx[2], jj & 63)
-                                                    : __builtin_amdgcn_readlane(S.pidx[3], jj & 63);
+                                                : __builtin_amdgcn_readlane(S.pidx[1], jj & 63);
                     {
-                        double car[kSlots];
+                        double car[kPS];
                         const int jbase = moff(jj);
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) {
+                        for (int s = 0; s < kPS; ++s) {
                             const int c = lane + kW * s;
                             car[s] = (c < jj) ? Mg[CK(jbase + c, kMSlab, 10, jj)] : 0.0;
                         }
-                        double carq = jj < kW ? rl(S.q[0], jj & 63) : jj < 2 * kW ? rl(S.q[1], jj & 63)
-                                    : jj < 3 * kW ? rl(S.q[2], jj & 63) : rl(S.q[3], jj & 63);
-                        double qsh[kSlots];
+                        double carq = jj < kW ? rl(S.q[0], jj & 63) : rl(S.q[1], jj & 63);
+                        double qsh[kPS];
                         shift_down(S.q, qsh, lane);  // qsh[i] = q[i + 1]
                         // row i of the new factor from the carried combination and old row i + 1 (column jj dropped);
                         // the loads of four rows are in flight before the first rotation
@@ -696,30 +708,32 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                                 if (lane == ((i + r) & 63)) S.q[si] = oq;
                             }
                         };
-                        for_pos4(jj, pp - 1, four, one);
+                        for_pos4n<kPS>(jj, pp - 1, four, one);
                     }
                     // ---- drop position jj from x / pidx
                     {
-                        double xsh[kSlots];
-                        int psh[kSlots];
+                        double xsh[kPS];
+                        int psh[kPS];
                         shift_down(S.x, xsh, lane);
                         shift_down_i(S.pidx, psh, lane);
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) {
+                        for (int s = 0; s < kPS; ++s) {
                             const int i = lane + kW * s;
                             if (i >= jj && i < pp - 1) {
                                 S.x[s] = xsh[s];
                                 S.pidx[s] = psh[s];
                             }
-                            if (binof(lane, s) == bin_out) S.inP[s] = false;
                         }
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s)
+                            if (binof(lane, s) == bin_out) S.inP[s] = false;
                     }
                     S.p = pp - 1;
                     wave_sync();
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
-                    for (int s = kSlots - 1; s >= 0; --s) {
+                    for (int s = kPS - 1; s >= 0; --s) {
                         const int i = lane + kW * s;
                         if (i < S.p && S.x[s] <= 0) bad = i;
                     }
@@ -731,12 +745,13 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 // ---- z = M^T q
                 {
                     const int nI = (S.p + 7) >> 3;
+                    const int lm = fresh(lane);
                     if (nI <= 2)
-                        mt_times_q<2>(Mg, xbuf, lane, la, lb, S);
+                        mt_times_q<2>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
                     else if (nI <= 4)
-                        mt_times_q<4>(Mg, xbuf, lane, la, lb, S);
+                        mt_times_q<4>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
                     else
-                        mt_times_q<6>(Mg, xbuf, lane, la, lb, S);
+                        mt_times_q<6>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
                 }
                 STAMP(6);
             }
@@ -761,16 +776,20 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             rn = sqrt(wave_sum(fma(r, r, tt)));
         } else
             rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
-        double *cv = A.coeff + (size_t)vox * n;
+        if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
+            if (lane == 0) A.bail[atomicAdd(A.n_bail, 1)] = (int32_t)vox;
+        } else {
+            double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
-            const int j = binof(lane, s);
-            if (j < n) cv[j] = xb[s];
-        }
-        if (lane == 0) {
-            A.rnorm[vox] = rn;
-            if (A.status) A.status[vox] = (int8_t)status;
-            if (A.iters) A.iters[vox] = iteration;
+            for (int s = 0; s < kSlots; ++s) {
+                const int j = binof(lane, s);
+                if (j < n) cv[j] = xb[s];
+            }
+            if (lane == 0) {
+                A.rnorm[vox] = rn;
+                if (A.status) A.status[vox] = (int8_t)status;
+                if (A.iters) A.iters[vox] = iteration;
+            }
         }
         STAMP(8);
     }
@@ -792,8 +811,8 @@ bool nnls_blk_applicable(const NnlsPlanData *P) {
     return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && getenv("PNX_NNLS_BLK");  // opt-in while it is tuned
 }
 
-// scratch of the block kernel: one workgroup of 16 waves per CU, kMSlab doubles of M per wave (zero initialised: the block
-// sweeps read whole blocks, also rows no voxel of this wave has written yet)
+// scratch of the block kernel: one workgroup of kBlkWaves waves per CU, kMSlab doubles of M per wave (zero initialised: the
+// block sweeps read whole blocks, also rows no voxel of this wave has written yet)
 int nnls_blk_plan_init(NnlsPlanData *P) {
     PNX_HIPB(hipFuncSetAttribute((const void *)nnls_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes()));
     int occ = 0;
@@ -803,34 +822,45 @@ int nnls_blk_plan_init(NnlsPlanData *P) {
     const size_t bytes = (size_t)P->blk_groups * kBlkWaves * kMSlab * sizeof(double);
     PNX_HIPB(hipMalloc(&P->Mblk, bytes));
     PNX_HIPB(hipMemset(P->Mblk, 0, bytes));
+    PNX_HIPB(hipMalloc(&P->blk_bail, (1 + (size_t)kAtyChunk) * sizeof(int32_t)));  // [0]: count, [1 ..]: voxel indices
+    PNX_HIPB(hipMemset(P->blk_bail, 0, sizeof(int32_t)));
     return PNX_OK;
 }
 
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                           int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
-    if (n_vox <= 0) return PNX_OK;
-    BlkArgs a;
-    a.y = y_d;
-    a.coeff = coeff_d;
-    a.rnorm = rnorm_d;
-    a.status = status_d;
-    a.iters = iters_d;
-    a.G = P->G;
-    a.Bp = P->Bp;
-    a.Mglob = P->Mblk;
-    a.queue = P->queue;
-    a.n_vox = n_vox;
-    a.n_meas = P->n_meas;
-    a.n_bins = P->n_bins;
-    a.n_reg = P->n_reg;
-    a.max_iter = max_iter;
-    for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
-    a.rhb = P->rhb;
-    PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-    long long grid = (n_vox + kBlkWaves - 1) / kBlkWaves;
-    if (grid > P->blk_groups) grid = P->blk_groups;
-    hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
-    PNX_HIPB(hipGetLastError());
+    // chunks of kAtyChunk voxels: the list of handed-over voxels is sized for one chunk
+    for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
+        const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
+        BlkArgs a;
+        a.y = y_d + (size_t)off * P->n_meas;
+        a.coeff = coeff_d + (size_t)off * P->n_bins;
+        a.rnorm = rnorm_d + off;
+        a.status = status_d ? status_d + off : nullptr;
+        a.iters = iters_d ? iters_d + off : nullptr;
+        a.G = P->G;
+        a.Bp = P->Bp;
+        a.Mglob = P->Mblk;
+        a.n_bail = P->blk_bail;
+        a.bail = P->blk_bail + 1;
+        a.queue = P->queue;
+        a.n_vox = c;
+        a.n_meas = P->n_meas;
+        a.n_bins = P->n_bins;
+        a.n_reg = P->n_reg;
+        a.max_iter = max_iter;
+        for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+        a.rhb = P->rhb;
+        PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
+        PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
+        long long grid = (c + kBlkWaves - 1) / kBlkWaves;
+        if (grid > P->blk_groups) grid = P->blk_groups;
+        hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
+        PNX_HIPB(hipGetLastError());
+        // voxels whose passive set outgrew this kernel (a few in 10^4 on the reference workload): the general kernel, from scratch
+        const int rc = nnls_redo_device(P, c, a.y, max_iter, a.coeff, a.rnorm, a.status, a.iters, P->blk_bail + 1, P->blk_bail, stream);
+        if (rc != PNX_OK) return rc;
+    }
     return PNX_OK;
 }
 

@@ -124,6 +124,19 @@ template <int S, class F4, class F1> __device__ inline void pos_range4(int lo, i
     for (; i + 4 <= b; i += 4) f4(i, SlotTag<S>{});
     for (; i < b; ++i) f1(i, SlotTag<S>{});
 }
+// the same for vectors of NS slots (positions < 64 NS)
+template <int NS, class F4, class F1> __device__ inline void for_pos4n(int lo, int hi, F4 &&f4, F1 &&f1) {
+    pos_range4<0>(lo, hi, f4, f1);
+    if constexpr (NS > 1) {
+        if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
+    }
+    if constexpr (NS > 2) {
+        if (hi > 2 * kW) pos_range4<2>(lo, hi, f4, f1);
+    }
+    if constexpr (NS > 3) {
+        if (hi > 3 * kW) pos_range4<3>(lo, hi, f4, f1);
+    }
+}
 template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4 &&f4, F1 &&f1) {
     pos_range4<0>(lo, hi, f4, f1);
     if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
@@ -133,28 +146,28 @@ template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4
 // write v at (uniform) position pos.  Written as per-lane selects on purpose: the obvious "if ((pos >> 6) == s) a[s] = v"
 // chain is folded by the optimiser into ONE store with a run-time index, which demotes the whole array from registers
 // to scratch memory (and every later access to it onto the vector-memory pipe, the busiest unit of this kernel).
-__device__ inline void put(double (&a)[kSlots], int pos, double v, int lane) {
+template <int NS> __device__ inline void put(double (&a)[NS], int pos, double v, int lane) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
+    for (int s = 0; s < NS; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
 }
-__device__ inline void put_i(int (&a)[kSlots], int pos, int v, int lane) {
+template <int NS> __device__ inline void put_i(int (&a)[NS], int pos, int v, int lane) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
+    for (int s = 0; s < NS; ++s) a[s] = (pos == lane + kW * s) ? v : a[s];
 }
 // position i receives the value of position i + 1 (the last position receives garbage)
-__device__ inline void shift_down(const double (&a)[kSlots], double (&out)[kSlots], int lane) {
+template <int NS> __device__ inline void shift_down(const double (&a)[NS], double (&out)[NS], int lane) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < NS; ++s) {
         double v = __shfl_down(a[s], 1);
-        const double nxt0 = (s + 1 < kSlots) ? rl(a[s + 1 < kSlots ? s + 1 : s], 0) : 0.0;
+        const double nxt0 = (s + 1 < NS) ? rl(a[s + 1 < NS ? s + 1 : s], 0) : 0.0;
         out[s] = (lane == 63) ? nxt0 : v;
     }
 }
-__device__ inline void shift_down_i(const int (&a)[kSlots], int (&out)[kSlots], int lane) {
+template <int NS> __device__ inline void shift_down_i(const int (&a)[NS], int (&out)[NS], int lane) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < NS; ++s) {
         int v = __shfl_down(a[s], 1);
-        const int nxt0 = (s + 1 < kSlots) ? __builtin_amdgcn_readlane(a[s + 1 < kSlots ? s + 1 : s], 0) : 0;
+        const int nxt0 = (s + 1 < NS) ? __builtin_amdgcn_readlane(a[s + 1 < NS ? s + 1 : s], 0) : 0;
         out[s] = (lane == 63) ? nxt0 : v;
     }
 }
@@ -187,9 +200,9 @@ template <bool REV> __device__ __forceinline__ void band5(const double *q, const
     o0 = a;
     o1 = b;
 }
-template <bool WANT_U>
-__device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[kSlots],
-                                 const int (&pidx)[kSlots], double (&u)[kSlots], double *tt) {
+template <bool WANT_U, int NS>
+__device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[NS],
+                                 const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
     // bin b lives at xbuf[2 + b]; two zero doubles in front of bin 0 and behind bin 255
     const double2 zero2 = {0.0, 0.0};
     double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
@@ -198,7 +211,7 @@ __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], in
     if (lane < 2) *reinterpret_cast<double2 *>(xbuf + 258 * lane) = zero2;
     lds_order();
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s)
+    for (int s = 0; s < NS; ++s)
         if (lane + kW * s < p) xbuf[2 + pidx[s]] = x[s];
     lds_order();
     double t[kSlots];
