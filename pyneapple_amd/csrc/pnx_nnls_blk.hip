@@ -93,7 +93,12 @@ __host__ __device__ constexpr int moff(int i) {
 static_assert(kMSlab >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
 
 // ---- reductions over one axis of the 8 x 8 lane grid (every lane of the group gets the sum) ----------------
-template <int CTRL> __device__ __forceinline__ double dppx(double v) { return dpp_mov<CTRL, 0xf, false>(v); }
+// a DPP lane permutation (every lane has a source): no `old` operand, so no register copy in front of the move
+template <int CTRL> __device__ __forceinline__ double dppx(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double swap_add16(double v) {  // + the lane 16 away (rows of 16 lanes swapped pairwise)
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
@@ -126,6 +131,31 @@ __device__ __forceinline__ double allreduce_a(double v) {
     return v;
 }
 
+// Reduce-scatter over a: v[K] is lane (a, b)'s partial sum of column block K; returned is, in the lanes of lane row a, the
+// total of block K = a -- which is position order (position 8 a + b lives in lane 8 a + b).  A swap of two registers
+// moves two blocks per step where an all-reduce would move one: 25 instructions for eight blocks instead of 15 per block.
+__device__ __forceinline__ double rs32(double x, double y) {  // lanes < 32: x + x(lane + 32); lanes >= 32: y + y(lane - 32)
+    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double rs16(double x, double y) {  // even rows of 16 lanes: x + x(next row); odd rows: y + y(previous row)
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+template <int NI> __device__ __forceinline__ double reduce_scatter_a(const double (&v)[NI], int la) {
+    static_assert(NI <= 8, "eight lane rows");
+    double R[4], Q[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) R[j] = j < NI ? rs32(v[j], j + 4 < NI ? v[j + 4 < NI ? j + 4 : 0] : 0.0) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) Q[j] = rs16(R[j], R[j + 2]);
+    const bool odd = la & 1;
+    const double keep = odd ? Q[1] : Q[0], send = odd ? Q[0] : Q[1];
+    return keep + dppx<0x128>(send);
+}
+
 // ---- products with the LDS-resident basis ------------------------------------------------------------------
 // stage x / pidx by position (zeros behind position p up to the end of its slot)
 __device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kPS],
@@ -140,7 +170,8 @@ __device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, 
     }
 }
 // every lane: (B_P x_P)[m], m = lane & 31.  Half wave h takes the positions h, h + 2, ...; the trip count is the same for
-// both halves (the staged arrays are zero padded), so the loop is a scalar one
+// both halves (the staged arrays are zero padded), so the loops are scalar ones.  Eight positions per half and step: the
+// x / bin reads of a step and then its eight column gathers are in flight together.
 __device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs, const lds_int *ps, int p, int lane) {
     const int m = lane & 31, h = lane >> 5;
     const double *Bm = Bl + m * kBStride;
@@ -149,40 +180,93 @@ __device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs,
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const int p2 = (p + 1) & ~1;  // rounded up to a pair: the pad entry holds x = 0, bin 0
     int i = 0;
-    for (; i + 8 <= p2; i += 8) {
-        const double x0 = xh[i], x1 = xh[i + 2], x2 = xh[i + 4], x3 = xh[i + 6];
-        const int j0 = ph[i], j1 = ph[i + 2], j2 = ph[i + 4], j3 = ph[i + 6];
-        a0 = fma(x0, Bm[j0], a0);
-        a1 = fma(x1, Bm[j1], a1);
-        a2 = fma(x2, Bm[j2], a2);
-        a3 = fma(x3, Bm[j3], a3);
+    for (; i + 16 <= p2; i += 16) {
+        double xv[8], bv[8];
+        int jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xv[u] = xh[i + 2 * u];
+            jv[u] = ph[i + 2 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = Bm[jv[u]];
+        a0 = fma(xv[0], bv[0], a0);
+        a1 = fma(xv[1], bv[1], a1);
+        a2 = fma(xv[2], bv[2], a2);
+        a3 = fma(xv[3], bv[3], a3);
+        a0 = fma(xv[4], bv[4], a0);
+        a1 = fma(xv[5], bv[5], a1);
+        a2 = fma(xv[6], bv[6], a2);
+        a3 = fma(xv[7], bv[7], a3);
+    }
+    if (i + 8 <= p2) {
+        double xv[4], bv[4];
+        int jv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = xh[i + 2 * u];
+            jv[u] = ph[i + 2 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = Bm[jv[u]];
+        a0 = fma(xv[0], bv[0], a0);
+        a1 = fma(xv[1], bv[1], a1);
+        a2 = fma(xv[2], bv[2], a2);
+        a3 = fma(xv[3], bv[3], a3);
+        i += 8;
     }
     for (; i < p2; i += 2) a0 = fma(xh[i], Bm[ph[i]], a0);
     return swap_add32((a0 + a1) + (a2 + a3));
 }
-// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS.  Four rows of B (eight ds_read_b128) are in
-// flight while the previous four are consumed.
+// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS.  Two groups of four rows (eight ds_read_b128
+// each) alternate: one is in flight while the other is consumed.
 __device__ __forceinline__ void bt_times(const double *Bl, const double *v, int lane, double (&out)[kSlots]) {
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) out[s] = 0;
     const double *col = Bl + 2 * lane;
+    double2 c0[4], c1[4], d0[4], d1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
+        c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
+    }
 #pragma unroll 1
-    for (int m = 0; m < kBMeas; m += 4) {
-        double2 c0[4], c1[4];
+    for (int m = 0; m < kBMeas; m += 8) {
+        const double *nx = col + (m + 4) * kBStride;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            c0[r] = *reinterpret_cast<const double2 *>(col + (m + r) * kBStride);
-            c1[r] = *reinterpret_cast<const double2 *>(col + (m + r) * kBStride + 128);
+            d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
+            d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
         }
-        const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
-        const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
-        const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+        {
+            const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
+            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
+            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[0] = fma(c0[r].x, vv[r], out[0]);
+                out[1] = fma(c0[r].y, vv[r], out[1]);
+                out[2] = fma(c1[r].x, vv[r], out[2]);
+                out[3] = fma(c1[r].y, vv[r], out[3]);
+            }
+        }
+        const double *ny = col + ((m + 8) & (kBMeas - 1)) * kBStride;  // the last step re-reads rows 0 .. 3 (unused)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            out[0] = fma(c0[r].x, vv[r], out[0]);
-            out[1] = fma(c0[r].y, vv[r], out[1]);
-            out[2] = fma(c1[r].x, vv[r], out[2]);
-            out[3] = fma(c1[r].y, vv[r], out[3]);
+            c0[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride);
+            c1[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride + 128);
+        }
+        {
+            const double2 v01 = *reinterpret_cast<const double2 *>(v + m + 4);
+            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 6);
+            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[0] = fma(d0[r].x, vv[r], out[0]);
+                out[1] = fma(d0[r].y, vv[r], out[1]);
+                out[2] = fma(d1[r].x, vv[r], out[2]);
+                out[3] = fma(d1[r].y, vv[r], out[3]);
+            }
         }
     }
 }
@@ -239,6 +323,7 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const l
     const int p2d = p < kRows2D ? p : kRows2D;
     const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
     double blk[NI][NI];
+    wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
     load_blocks<NI>(Mg, la, lb, blk);
     const double Gjj = uni(grow[CK(jmax, kNnlsMaxBins, 2, p)]);
     // g in column layout: lane (a, b) holds g_{8 K + b}
@@ -336,33 +421,19 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const l
 #ifdef PNX_NNLS_TRACE
     if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) printf("A p=%d j=%d lam=%.17g qn=%.17g\n", p, jmax, lam, qn);
 #endif
-    // column sums: over a, then to position order (position 8 la + lb is column K = la, b = lb)
-    double r2d = 0;
-#pragma unroll
-    for (int K = 0; K < NI; ++K) {
-        rK[K] = allreduce_a(rK[K]);
-        r2d = (la == K) ? rK[K] : r2d;
-    }
-    a1[0] += r2d;
-    // the new row (padded to the block boundary with zeros) and the rank-one update of the solution
-    if (NI < 6 || p < kRows2D) {
-        if (la == (p & 7)) {
-            const int pbase = moff(p) + lb;
-#pragma unroll
-            for (int K = 0; K < NI; ++K) {
-                const int k = 8 * K + lb;
-                if (K <= (p >> 3)) Mg[CK(pbase + 8 * K, kMSlab, 7, p)] = k < p ? -rK[K] * ilam : (k == p ? ilam : 0.0);
-            }
-        }
-    } else {
+    // column sums over a, delivered in position order (position 8 la + lb is column block K = la)
+    a1[0] += reduce_scatter_a<NI>(rK, la);
+    // the new row (padded to the block boundary with zeros)
+    {
         const int pbase = moff(p);
         const int width = 8 * ((p >> 3) + 1);
 #pragma unroll
         for (int s = 0; s < kPS; ++s) {
             const int k = lane + kW * s;
-            if (k < width) Mg[CK(pbase + k, kMSlab, 8, p)] = k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0);
+            if ((s == 0 || p >= kW) && k < width) Mg[CK(pbase + k, kMSlab, 8, p)] = k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0);
         }
     }
+    // the rank-one update of the solution
 #pragma unroll
     for (int s = 0; s < kPS; ++s) {
         const int k = lane + kW * s;
@@ -388,6 +459,7 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const int p2d = p < kRows2D ? p : kRows2D;
     double blk[NI][NI];
+    wave_sync();
     load_blocks<NI>(Mg, la, lb, blk);
     lds_order();
     stg[lane] = S.q[0];
@@ -399,16 +471,14 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
         qr[I] = (8 * I + la < p2d) ? v : 0.0;
     }
     lds_order();
-    double z0 = 0;
+    double zK[NI];
 #pragma unroll
     for (int K = 0; K < NI; ++K) {
-        double acc = 0;
+        zK[K] = 0;
 #pragma unroll
-        for (int I = K; I < NI; ++I) acc = fma(blk[I][K], qr[I], acc);
-        acc = allreduce_a(acc);
-        z0 = (la == K) ? acc : z0;
+        for (int I = K; I < NI; ++I) zK[K] = fma(blk[I][K], qr[I], zK[K]);
     }
-    S.z[0] = z0;
+    S.z[0] = reduce_scatter_a<NI>(zK, la);
 #pragma unroll
     for (int s = 1; s < kPS; ++s) S.z[s] = 0;
     if (NI == 6 && p > kRows2D) {
@@ -552,7 +622,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             }
             STAMP(2);
             if (!accepted) break;
-            wave_sync();
             STAMP(3);
 
             // ---- inner loop: keep the passive-set solution feasible
@@ -610,15 +679,22 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                     const int pp = __builtin_amdgcn_readfirstlane(S.p);
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-                    double mv[kPS], pre[kPS];
+                    double mv[kPS], pre[kPS], car[kPS];
                     double carry = 0;
+                    wave_sync();
+                    {
+                        const int jbase = moff(jj);
+#pragma unroll
+                        for (int s = 0; s < kPS; ++s) {  // column jj (rows jj ..) and row jj (columns < jj): both reads in flight
+                            const int i = lane + kW * s;
+                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? Mg[CK(moff(i) + jj, kMSlab, 9, i)] : 0.0;
+                            car[s] = (i < jj) ? Mg[CK(jbase + i, kMSlab, 10, jj)] : 0.0;
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < kPS; ++s) {
-                        const int i = lane + kW * s;
-                        mv[s] = 0;
                         pre[s] = carry;
                         if (kW * s < pp) {
-                            if (i >= jj && i < pp) mv[s] = Mg[CK(moff(i) + jj, kMSlab, 9, i)];
                             const double sc = wave_incl_scan(mv[s] * mv[s]);
                             pre[s] = sc + carry;
                             carry += rl(sc, 63);
@@ -634,54 +710,29 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                         cs[s] = 1.0;
                         sn[s] = 0.0;
                         if (i >= jj && i < pp - 1) {
-                            const double a = (i == jj) ? mv[s] : sqrt(pre[s]);  // first carried value keeps its sign
-                            const double b = mnext[s];
-                            const double r = sqrt(prenext[s]);
-                            if (r > 0) {
-                                cs[s] = b / r;
-                                sn[s] = a / r;
+                            // a = sqrt(pre) (the first carried value keeps its sign), r = sqrt(prenext): c = m_next / r, s = a / r
+                            const double ir = prenext[s] > 0 ? rsqrt_nr(prenext[s]) : 0.0;
+                            const double a = (i == jj) ? mv[s] : (pre[s] > 0 ? pre[s] * rsqrt_nr(pre[s]) : 0.0);
+                            if (prenext[s] > 0) {
+                                cs[s] = mnext[s] * ir;
+                                sn[s] = a * ir;
                             }
                         }
                     }
                     const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
                                                 : __builtin_amdgcn_readlane(S.pidx[1], jj & 63);
                     {
-                        double car[kPS];
-                        const int jbase = moff(jj);
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s) {
-                            const int c = lane + kW * s;
-                            car[s] = (c < jj) ? Mg[CK(jbase + c, kMSlab, 10, jj)] : 0.0;
-                        }
                         double carq = jj < kW ? rl(S.q[0], jj & 63) : rl(S.q[1], jj & 63);
                         double qsh[kPS];
                         shift_down(S.q, qsh, lane);  // qsh[i] = q[i + 1]
                         // row i of the new factor from the carried combination and old row i + 1 (column jj dropped);
-                        // the loads of four rows are in flight before the first rotation
-                        auto one = [&](int i, auto T) {
+                        // the loads of a batch of rows are in flight before its first rotation
+                        auto rows = [&](int i, auto T, auto NB) {
                             constexpr int si = decltype(T)::value;
-                            const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
-                            const double qnx = rl(qsh[si], i & 63);
-                            const int nbase = moff(i + 1), obase = moff(i);
+                            constexpr int nb = decltype(NB)::value;
+                            double nx[nb][si + 1];
 #pragma unroll
-                            for (int s = 0; s <= si; ++s) {
-                                const int c = lane + kW * s;
-                                const double nxt = Mg[CK(nbase + (c < jj ? c : c + 1), kMSlab, 11, i)];
-                                if (c <= i) {
-                                    const double outv = c_ * car[s] - s_ * nxt;
-                                    car[s] = s_ * car[s] + c_ * nxt;
-                                    Mg[CK(obase + c, kMSlab, 12, i)] = outv;
-                                }
-                            }
-                            const double oq = c_ * carq - s_ * qnx;
-                            carq = s_ * carq + c_ * qnx;
-                            if (lane == (i & 63)) S.q[si] = oq;
-                        };
-                        auto four = [&](int i, auto T) {
-                            constexpr int si = decltype(T)::value;
-                            double nx[4][si + 1];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
+                            for (int r = 0; r < nb; ++r) {
                                 const int nbase = moff(i + r + 1);
 #pragma unroll
                                 for (int s = 0; s <= si; ++s) {
@@ -690,7 +741,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                                 }
                             }
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
+                            for (int r = 0; r < nb; ++r) {
                                 const double c_ = rl(cs[si], (i + r) & 63), s_ = rl(sn[si], (i + r) & 63);
                                 const double qnx = rl(qsh[si], (i + r) & 63);
                                 const int obase = moff(i + r);
@@ -708,7 +759,22 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                                 if (lane == ((i + r) & 63)) S.q[si] = oq;
                             }
                         };
-                        for_pos4n<kPS>(jj, pp - 1, four, one);
+                        const int hi = pp - 1;
+                        {   // rows < 64: one register per row and lane, eight rows per step
+                            const int e = hi < kW ? hi : kW;
+                            int i = jj;
+                            for (; i + 8 <= e; i += 8) rows(i, SlotTag<0>{}, SlotTag<8>{});
+                            if (i + 4 <= e) {
+                                rows(i, SlotTag<0>{}, SlotTag<4>{});
+                                i += 4;
+                            }
+                            for (; i < e; ++i) rows(i, SlotTag<0>{}, SlotTag<1>{});
+                        }
+                        if (hi > kW) {
+                            int i = jj > kW ? jj : kW;
+                            for (; i + 4 <= hi; i += 4) rows(i, SlotTag<1>{}, SlotTag<4>{});
+                            for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{});
+                        }
                     }
                     // ---- drop position jj from x / pidx
                     {
