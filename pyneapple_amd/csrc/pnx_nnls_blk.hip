@@ -36,7 +36,7 @@ namespace pnx {
 constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
 constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
 #ifndef PNX_BLK_WAVES
-#define PNX_BLK_WAVES 16
+#define PNX_BLK_WAVES 12  // 168 registers per wave: 16 waves (128 registers) spill in every phase and run 17 % slower
 #endif
 constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU
 constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
@@ -115,6 +115,26 @@ __device__ __forceinline__ double swap_add32(double v) {  // + the lane 32 away
 // condition around DPP / readlane / permlane code makes the compiler mask a loop that no lane ever leaves alone)
 __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// maximum over the wave, in every lane
+__device__ __forceinline__ double allreduce_max(double v) {
+    v = fmax(v, dppx<0xB1>(v));
+    v = fmax(v, dppx<0x4E>(v));
+    v = fmax(v, dppx<0x141>(v));
+    v = fmax(v, dppx<0x128>(v));
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    return v;
 }
 // over b = lane & 7: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
 __device__ __forceinline__ double allreduce_b(double v) {
@@ -320,7 +340,6 @@ template <int NI>
 __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const lds_int *ps, int lane, int la, int lb, int jmax,
                                            double wj, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
-    const int p2d = p < kRows2D ? p : kRows2D;
     const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
     double blk[NI][NI];
     wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
@@ -329,12 +348,9 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const l
     // g in column layout: lane (a, b) holds g_{8 K + b}
     double gc[NI];
 #pragma unroll
-    for (int K = 0; K < NI; ++K) {
+    for (int K = 0; K < NI; ++K) {  // no mask: behind position p the staged bins are 0 and the columns of M are zero
         const int k = 8 * K + lb;
-        const bool ok = k < p2d;
-        const int j = ok ? ps[k] : 0;
-        const double gv = grow[CK(j, kNnlsMaxBins, 3, k)];
-        gc[K] = ok ? gv : 0.0;
+        gc[K] = grow[CK(ps[k], kNnlsMaxBins, 3, k)];
     }
     double rK[NI];  // column sums of l^T M, lane (a, b) holds the partial sum over its rows of column 8 K + b
 #pragma unroll
@@ -345,8 +361,7 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const l
         double acc = 0;
 #pragma unroll
         for (int K = 0; K <= I; ++K) acc = fma(blk[I][K], gc[K], acc);
-        acc = allreduce_b(acc);
-        const double lr = (8 * I + la < p2d) ? acc : 0.0;  // l_{8 I + a}, the same in the lanes (a, *)
+        const double lr = allreduce_b(acc);  // l_{8 I + a}, the same in the lanes (a, *); rows >= p of M are zero
         ll = fma(lr, lr, ll);
 #pragma unroll
         for (int K = 0; K <= I; ++K) rK[K] = fma(blk[I][K], lr, rK[K]);
@@ -457,7 +472,6 @@ __device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const l
 template <int NI>
 __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, int la, int lb, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
-    const int p2d = p < kRows2D ? p : kRows2D;
     double blk[NI][NI];
     wave_sync();
     load_blocks<NI>(Mg, la, lb, blk);
@@ -466,10 +480,7 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
     lds_order();
     double qr[NI];
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
-        const double v = stg[8 * I + la];
-        qr[I] = (8 * I + la < p2d) ? v : 0.0;
-    }
+    for (int I = 0; I < NI; ++I) qr[I] = stg[8 * I + la];  // rows >= p of M are zero: what q holds there does not matter
     lds_order();
     double zK[NI];
 #pragma unroll
@@ -591,16 +602,20 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             bool accepted = false;
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
-                double best = -INFINITY;
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) best = fmax(best, w[s]);
-                best = wave_max(best);
+                const double best = uni(allreduce_max(fmax(fmax(w[0], w[1]), fmax(w[2], w[3]))));
                 if (!(best > 0)) break;  // KKT satisfied
-                int bj = kNone;
-#pragma unroll
-                for (int s = kSlots - 1; s >= 0; --s)
-                    if (w[s] == best) bj = binof(lane, s);
-                const int jmax = wave_min_i(bj);
+                // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
+                int jmax = kNone;
+                {
+                    const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
+                    const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
+                    const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
+                    const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
+                    const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
+                    const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
+                    const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
+                    jmax = lo < hi ? lo : hi;
+                }
                 if (jmax == kNone) break;  // cannot happen (some lane holds the maximum); never index G with it
                 if (S.p >= kMaxPos) {      // no room for another column in this kernel's registers
                     status = kBail;
@@ -794,8 +809,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                         for (int s = 0; s < kSlots; ++s)
                             if (binof(lane, s) == bin_out) S.inP[s] = false;
                     }
+                    {   // the vacated last row: rows >= p of M stay zero (the block sweeps carry no row masks)
+                        const int vbase = moff(pp - 1);
+                        const int width = 8 * (((pp - 1) >> 3) + 1);
+#pragma unroll
+                        for (int s = 0; s < kPS; ++s)
+                            if (lane + kW * s < width) Mg[CK(vbase + lane + kW * s, kMSlab, 15, pp)] = 0.0;
+                    }
                     S.p = pp - 1;
-                    wave_sync();
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
@@ -824,6 +845,15 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
         }
         STAMP(7);
 
+        // ---- the next voxel starts from an all-zero M
+        {
+            const int pe = __builtin_amdgcn_readfirstlane(S.p);
+            for (int i = 0; i < pe; ++i) {
+                const int width = 8 * ((i >> 3) + 1);
+                if (lane < width) Mg[moff(i) + lane] = 0.0;
+                if (i >= kW && lane + kW < width) Mg[moff(i) + lane + kW] = 0.0;
+            }
+        }
         // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
         double xb[kSlots] = {0, 0, 0, 0};
         double rn;
@@ -874,7 +904,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
 static size_t blk_lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * kScr); }
 
 bool nnls_blk_applicable(const NnlsPlanData *P) {
-    return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && getenv("PNX_NNLS_BLK");  // opt-in while it is tuned
+    return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && !getenv("PNX_NNLS_NO_BLK");
 }
 
 // scratch of the block kernel: one workgroup of kBlkWaves waves per CU, kMSlab doubles of M per wave (zero initialised: the

@@ -181,7 +181,7 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 // v by position (x, pidx, p).  Returns u by bin in `u`, and sum t^2 of this lane's bins in *tt.  A lane owns the bin
 // pairs (2 l, 2 l + 1) and (128 + 2 l, 129 + 2 l): three 16-byte reads per pair bring the pair and its two neighbours
 // on either side.
-template <bool REV> __device__ __forceinline__ void band5(const double *q, const double (&c)[5], int hb, double &o0, double &o1) {
+template <bool REV, int HB> __device__ __forceinline__ void band5(const double *q, const double (&c)[5], double &o0, double &o1) {
     // q points at the pair; taps d = -2 .. 2 of out_j = sum_d c[d + 2] v[j + d]  (REV: c[2 - d], the transposed band)
     const double2 lo = *reinterpret_cast<const double2 *>(q - 2), mid = *reinterpret_cast<const double2 *>(q),
                   hi = *reinterpret_cast<const double2 *>(q + 2);
@@ -191,7 +191,7 @@ template <bool REV> __device__ __forceinline__ void band5(const double *q, const
     b = fma(c[2], mid.y, b);
     a = fma(cp1, mid.y, a);
     b = fma(cp1, hi.x, b);
-    if (hb > 1) {
+    if (HB > 1) {
         a = fma(cm2, lo.x, a);
         b = fma(cm2, lo.y, b);
         a = fma(cp2, hi.x, a);
@@ -200,9 +200,9 @@ template <bool REV> __device__ __forceinline__ void band5(const double *q, const
     o0 = a;
     o1 = b;
 }
-template <bool WANT_U, int NS>
-__device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[NS],
-                                 const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
+template <bool WANT_U, int HB, int NS>
+__device__ __forceinline__ void reg_terms_hb(double *xbuf, const double (&c)[5], int n, int p, int lane, const double (&x)[NS],
+                                    const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
     // bin b lives at xbuf[2 + b]; two zero doubles in front of bin 0 and behind bin 255
     const double2 zero2 = {0.0, 0.0};
     double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
@@ -215,8 +215,8 @@ __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], in
         if (lane + kW * s < p) xbuf[2 + pidx[s]] = x[s];
     lds_order();
     double t[kSlots];
-    band5<false>(lo, c, hb, t[0], t[1]);
-    band5<false>(hi, c, hb, t[2], t[3]);
+    band5<false, HB>(lo, c, t[0], t[1]);
+    band5<false, HB>(hi, c, t[2], t[3]);
     double acc = 0;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -229,9 +229,18 @@ __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], in
     *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
     *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
     lds_order();
-    band5<true>(lo, c, hb, u[0], u[1]);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
-    band5<true>(hi, c, hb, u[2], u[3]);
+    band5<true, HB>(lo, c, u[0], u[1]);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    band5<true, HB>(hi, c, u[2], u[3]);
     lds_order();
+}
+// hb (wave uniform): half bandwidth of the regulariser, 1 (orders 1 and 2 of the reference) or 2 (order 3)
+template <bool WANT_U, int NS>
+__device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[NS],
+                                 const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
+    if (hb > 1)
+        reg_terms_hb<WANT_U, 2>(xbuf, c, n, p, lane, x, pidx, u, tt);
+    else
+        reg_terms_hb<WANT_U, 1>(xbuf, c, n, p, lane, x, pidx, u, tt);
 }
 
 }  // namespace pnx
