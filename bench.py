@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (half the 157.3 TF fp32 rate of MI355X_MICROARCH.md)
 METRIC = "voxels/sec (pixelwise triexp LM & 250-bin NNLS) at 1/2/4/8 MI355X"
 CURVEFIT_C3_KERNEL = "curvefit_kernel<4, 5, true, false, false>"  # rocprofv3's name of the C3 instantiation
+NNLS_KERNEL = "nnls_blk_kernel"  # the C4 plan (banded regulariser, 32 measurements): pnx_nnls_blk.hip
 
 
 def host_cores() -> int:
@@ -62,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--no-host-mode", action="store_true", help="skip the PCIe-inclusive host-pointer legs")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-passes-in-flight leg of the curve fit")
     ap.add_argument("--voxels", type=int, default=0, help="override the voxels of the volume (debug; marks the line invalid)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(launcher test) this rank exits with code 3 at start-up")
     ap.add_argument("--launch-check", action="store_true",
                     help="every rank prints its rank / world / shard as JSON and exits without touching the GPU")
     return ap.parse_args(argv)
@@ -82,12 +84,34 @@ def launch(args, argv) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 or args.launch_check else subprocess.DEVNULL))
+    # poll every rank: the first one that exits non-zero ends the run (a rank that dies at start-up would otherwise leave
+    # the others waiting in init_process_group / the barrier until the backend's own timeout)
     rc = 0
-    outs = []
+    alive = set(range(len(procs)))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write(f"bench.py: rank {r} exited with code {code}; stopping the other ranks\n")
+                for q in alive:
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.05)
+            if rc != 0:
+                deadline = time.time() + 10.0
+                while alive and time.time() < deadline:
+                    alive = {q for q in alive if procs[q].poll() is None}
+                    time.sleep(0.05)
+                for q in alive:
+                    procs[q].kill()
+                alive = set()
+    outs = [(p.stdout.read().decode() if p.stdout else "") for p in procs]
     for p in procs:
-        out, _ = p.communicate()
-        outs.append(out.decode() if out else "")
-        rc = rc or p.returncode
+        p.wait()
     sys.stdout.write("".join(outs) if args.launch_check else outs[0])
     sys.stdout.flush()
     return rc
@@ -201,6 +225,25 @@ class CurvefitLeg:
                 "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes), "d2h_bytes": int(d2h),
                 "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps, "equals_device_resident_result": same}
 
+    def host_mode_f32(self, reps=2):
+        """BASELINE's "fp32" configuration as a Pyneapple user runs it: float32 signal in, float32 popt / pcov / cost out through
+        pnx_curvefit_batch_f32 (fp64 arithmetic on the widened values; half of the PCIe bytes of host_mode)."""
+        y = self.y.cpu().numpy().astype(np.float32)
+        kw = dict(max_nfev=250, ftol=1e-8, jac=self.jac, want_pcov=self.want_pcov, device=self.device.index)
+        r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)
+        ts = []
+        for _ in range(reps):
+            del r
+            t = time.perf_counter()
+            r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)
+            ts.append(time.perf_counter() - t)
+        dt = float(np.mean(ts))
+        d2h = sum(a.nbytes for a in r.values() if a is not None)
+        return {"workload": "same volume as float32 numpy arrays in and out (pnx_curvefit_batch_f32, PNX_MEM_HOST)",
+                "value": self.n_vox / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes),
+                "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps,
+                "result_dtype": str(r["popt"].dtype), "converged_frac": float((r["status"] > 0).mean())}
+
     def cpu_baseline(self):
         """The oracle (C restatement of SciPy TRF) on the host cores, bounded sample of the same workload."""
         from oracle import pnx_oracle as O
@@ -242,7 +285,7 @@ class NnlsLeg:
         self.iters = torch.empty(self.n_vox, dtype=torch.int32, device=device)
         self.bytes_per_voxel = n_b * 8 + nb * 8 + 8 + 1 + 4
         self.dtype = "f64"
-        self.kernel = "nnls_kernel"
+        self.kernel = NNLS_KERNEL
         self.model = "nnls"
         self.device = device
 
@@ -293,6 +336,17 @@ class NnlsLeg:
             "value": n / dtp, "unit": "voxels/s", "ms_per_step": dtp * 1e3,
             "d2h_bytes": int(sum(a.nbytes for a in rp.values() if a is not None)),
             "mean_peaks_per_voxel": float(rp["n_peaks"].mean())}
+        del rp
+        # float32 storage (pnx_nnls_solve_f32): the signal goes in and the spectra come back as float32, half the PCIe bytes
+        y32 = y.astype(np.float32)
+        r = self.plan.solve(y32[: min(n, 1 << 16)], self.cfg["max_iter"])
+        del r
+        t = time.perf_counter()
+        r = self.plan.solve(y32, self.cfg["max_iter"])
+        dt32 = time.perf_counter() - t
+        out["f32"] = {"workload": "the same voxels as float32 arrays in and out (pnx_nnls_solve_f32)", "value": n / dt32,
+                      "unit": "voxels/s", "ms_per_step": dt32 * 1e3, "h2d_bytes": int(y32.nbytes),
+                      "d2h_bytes": int(sum(a.nbytes for a in r.values())), "result_dtype": str(r["coefficients"].dtype)}
         return out
 
     def cpu_baseline(self):
@@ -484,9 +538,12 @@ def main(argv=None):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; run `python bench.py --gpus {args.gpus}` "
                          f"(it spawns the ranks) or torch.distributed.run --nproc-per-node {args.gpus}\n")
         return 2
+    if args.fail_rank == rank:
+        return 3
     n_total, rows = volume_rows(args.workload, args, rank, world)
     if args.launch_check:
         print(json.dumps({"rank": rank, "world": world, "local_rank": local, "rows": rows, "n_vox_total": n_total}), flush=True)
+        time.sleep(float(os.environ.get("PNX_BENCH_LAUNCH_HOLD", "0")))  # launcher test: a rank that would wait for its peers
         return 0
 
     # stdout carries exactly ONE JSON line: whatever libraries print there (gloo / RCCL connection notes, ...) is sent to stderr
@@ -563,9 +620,17 @@ def main(argv=None):
                                        "source_id": fl["source_id"]}
     if args.workload != "nnls" and not args.no_pipelined:
         out["pipelined"] = leg.pipelined(max(args.steps, 4), world, dist)  # every rank takes part (barriers)
+        # `value` is the strong-scaling figure north_star asks for: ONE volume, one pass at a time, so at N ranks it ends in the
+        # straggler tail of an N-th of the volume.  `throughput` is what N ranks sustain on a queue of independent volumes
+        # (every rank keeps two passes of its shard in flight; same barriers, max over ranks): it separates "the tail of a
+        # short shard" from "the ranks interfere" when the two are compared over N
+        out["throughput"] = {"value": out["pipelined"]["value"], "unit": "voxels/s", "n_gpus": world,
+                             "mode": "two passes in flight per rank on its shard; voxels of the whole volume x passes / max over ranks"}
     solo = rank == 0 and world == 1
     if solo and not args.no_host_mode:
         out["host_mode"] = leg.host_mode()
+        if args.workload != "nnls":
+            out["host_mode_f32"] = leg.host_mode_f32()
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = leg.cpu_baseline()
     if args.workload == "triexp" and not args.no_secondary:
@@ -579,12 +644,12 @@ def main(argv=None):
         ach2 = leg2.bytes_per_voxel * leg2.n_vox / k2avg / 1e9
         sec = {"workload": WORKLOAD_TEXT["nnls"], "value": n2 * steps2 / dt2,
                "unit": "voxels/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "check": leg2.check(),
-               "roofline": {"bound": "hbm", "kernel": "nnls_kernel", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "roofline": {"bound": "hbm", "kernel": NNLS_KERNEL, "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach2 / HBM_PEAK_GBS,
                             "traffic": nnls_traffic(leg2.n_vox) if (not args.voxels and world == 1) else None,
                             "algorithmic_bytes_per_voxel": leg2.bytes_per_voxel, "kernel_ms_avg": k2avg * 1e3,
-                            "note": "bounded by voxels in flight per CU (16: LDS and VGPRs) x per-iteration latency, not by HBM (profiles/r02_nnls_experiments.md)"}}
-        fl2 = pmc_flops("nnls_kernel", "nnls")
+                            "note": "VALU issue (about 75 % busy at 12 waves per CU) and per-iteration latency bound, not HBM bound (DESIGN.md section 4.3)"}}
+        fl2 = pmc_flops(NNLS_KERNEL, "nnls")
         if fl2:
             tf2 = fl2["fp64_flop_per_voxel_issued"] * leg2.n_vox / k2avg / 1e12
             sec["roofline"]["valu_f64"] = {"achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf2 / FP64_PEAK_TFLOPS,
@@ -617,7 +682,7 @@ def nnls_traffic(n_vox):
     if not t:
         return None
     per = int(t.get("_nnls_launch_voxels", 1 << 20))
-    v = pmc_traffic("nnls_kernel", "nnls")
+    v = pmc_traffic(NNLS_KERNEL, "nnls")
     return None if v is None else v * ((n_vox + per - 1) // per)
 
 

@@ -211,6 +211,9 @@ def nnls_basis(b, bins, device=0):
     return out
 
 
+SPECTRUM_MAX_PEAKS = 16  # kMaxPeaks of csrc/pnx_spectrum.hip
+
+
 def spectrum_peaks(spectrum, bins, height=0.1, regularized=False, rel_height=0.5, max_peaks=8, cutoffs=None, device=0):
     """find_spectrum_peaks (+ apply_cutoffs) of utility/spectrum.py for every row of `spectrum` (n_vox, n_bins) at once, on
     the device.  numpy arrays in and out, or torch-cuda tensors for `spectrum` (then the outputs are torch tensors)."""
@@ -241,6 +244,12 @@ def spectrum_peaks(spectrum, bins, height=0.1, regularized=False, rel_height=0.5
                                              float(rel_height), int(max_peaks), ptr(out["n_peaks"]), ptr(out["d_values"]),
                                              ptr(out["f_values"]), n_cut, ptr(cut), ptr(out["d_cut"]), ptr(out["f_cut"]),
                                              MEM_DEVICE if tensor else MEM_HOST, int(device), stream))
+    if not tensor and n_vox and int(out["n_peaks"].max()) > SPECTRUM_MAX_PEAKS:
+        import warnings
+
+        k = int((out["n_peaks"] > SPECTRUM_MAX_PEAKS).sum())
+        warnings.warn(f"{k} spectra have more than {SPECTRUM_MAX_PEAKS} peaks (the device table's size): their peak and cutoff "
+                      f"rows are NaN; n_peaks holds the count", RuntimeWarning, stacklevel=2)
     return out
 
 

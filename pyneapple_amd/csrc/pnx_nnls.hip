@@ -800,6 +800,39 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
         bool zero = true;
         for (size_t i = 0; i < (size_t)n_reg * n_bins && zero; ++i) zero = reg[i] == 0.0;
         P->qr = zero && n_meas <= 64 && !getenv("PNX_NNLS_NO_QR");
+        // never a silently different algorithm: the QR-form kernel keeps one measurement per lane (<= 64 of them).  Beyond
+        // that the Gram form is only an answer when the basis is well conditioned (it works with cond(A)^2): a pivoted
+        // look at chol(B^T B) on the host decides, once per plan
+        if (zero && n_meas > 64 && !getenv("PNX_NNLS_NO_QR")) {
+            std::vector<double> Gh((size_t)n_bins * n_bins, 0.0);
+            for (int i = 0; i < n_bins; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double acc = 0;
+                    for (int k = 0; k < n_meas; ++k) acc += basis[(size_t)k * n_bins + i] * basis[(size_t)k * n_bins + j];
+                    Gh[(size_t)i * n_bins + j] = acc;
+                }
+            double gmax = 0, pmin = INFINITY;
+            for (int i = 0; i < n_bins; ++i) gmax = std::fmax(gmax, Gh[(size_t)i * n_bins + i]);
+            bool ok = n_meas >= n_bins && gmax > 0;
+            for (int i = 0; i < n_bins && ok; ++i) {  // plain Cholesky, in place
+                for (int j = 0; j <= i; ++j) {
+                    double acc = Gh[(size_t)i * n_bins + j];
+                    for (int k = 0; k < j; ++k) acc -= Gh[(size_t)i * n_bins + k] * Gh[(size_t)j * n_bins + k];
+                    if (j < i)
+                        Gh[(size_t)i * n_bins + j] = acc / Gh[(size_t)j * n_bins + j];
+                    else {
+                        pmin = std::fmin(pmin, acc);
+                        ok = acc > 1e-10 * gmax;  // cond(A)^2 beyond ~1e10: the Gram form has no digits to spare
+                        Gh[(size_t)i * n_bins + i] = ok ? std::sqrt(acc) : 1.0;
+                    }
+                }
+            }
+            if (!ok)
+                return set_error(PNX_ERR_UNSUPPORTED,
+                                 "NNLS without a regulariser (reg_order = 0 or mu = 0) and n_meas = %d > 64: the basis is rank "
+                                 "deficient or too ill conditioned for the normal-equation kernel (smallest Cholesky pivot %.3g of "
+                                 "%.3g); use a regulariser or at most 64 measurements", n_meas, pmin, gmax);
+        }
     }
     const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)kNnlsMaxBins * kNnlsMaxBins;
     for (size_t i = 0; i < nb; ++i)

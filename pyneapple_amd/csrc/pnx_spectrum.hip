@@ -79,6 +79,14 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
             ++i;
         }
     }
+    if (total > kMaxPeaks) {  // more peaks than the table holds: NaN everywhere rather than fractions normalised over a part
+        if (A.n_peaks) A.n_peaks[vox] = total;
+        if (A.d_values)
+            for (int k = 0; k < A.max_peaks; ++k) A.d_values[(size_t)vox * A.max_peaks + k] = A.f_values[(size_t)vox * A.max_peaks + k] = nan;
+        if (A.d_cut)
+            for (int c = 0; c < A.n_cut; ++c) A.d_cut[(size_t)vox * A.n_cut + c] = A.f_cut[(size_t)vox * A.n_cut + c] = nan;
+        return;
+    }
     // ---- fractions: raw heights, or the Gaussian area from the width at rel_height of the prominence
     double fv[kMaxPeaks], dv[kMaxPeaks];
     double fsum = 0;
@@ -275,6 +283,13 @@ __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
         }
         Mask4 peaks = ballot4(pk);
         const int total = __popcll(peaks.m[0]) + __popcll(peaks.m[1]) + __popcll(peaks.m[2]) + __popcll(peaks.m[3]);
+        if (total > kMaxPeaks) {  // more peaks than the table (one per lane 0..15) holds: NaN, never a partial normalisation
+            if (A.n_peaks && lane == 0) A.n_peaks[vox] = total;
+            if (A.d_values && lane < A.max_peaks) A.d_values[(size_t)vox * A.max_peaks + lane] = A.f_values[(size_t)vox * A.max_peaks + lane] = nan;
+            if (A.d_cut && lane < A.n_cut) A.d_cut[(size_t)vox * A.n_cut + lane] = A.f_cut[(size_t)vox * A.n_cut + lane] = nan;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            continue;
+        }
         // peak k of the list lives in lane k
         double dval = nan, fval = nan;
         int m = 0;

@@ -88,6 +88,23 @@ except Exception:
     _RefBaseFitter = None
 
 
+
+def validate_segmentation(segmentation, image_shape):
+    """utility/validation.py:133-149: one dimension less than the image; a trailing singleton axis (a NIfTI mask loaded as
+    4-D) is squeezed away, any other mismatch is a ValueError with the reference's wording."""
+    segmentation = np.asarray(segmentation)
+    spatial = tuple(image_shape[:-1])
+    if segmentation.ndim != len(image_shape) - 1:
+        if segmentation.ndim and segmentation.shape[-1] == 1:
+            segmentation = np.squeeze(segmentation, axis=-1)
+        else:
+            raise ValueError(f"Segmentation must have one less dimension than image shape {tuple(image_shape)}, "
+                             f"but got shape {segmentation.shape}.")
+    if segmentation.shape != spatial:
+        raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {spatial}.")
+    return segmentation
+
+
 class _StandInBaseFitter:
     """The state `BaseFitter.__init__` sets (fitters/base.py:39-62), for hosts without the reference installed."""
 
@@ -283,9 +300,7 @@ class HipPixelWiseFitter(HipFitterBase):
         if segmentation is None:
             mask = np.ones(spatial, dtype=bool)
         else:
-            segmentation = np.asarray(segmentation)
-            if segmentation.shape != spatial:
-                raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {spatial}.")
+            segmentation = validate_segmentation(segmentation, image.shape)
             mask = segmentation != 0
         if segmentation is None:  # every voxel: a view, not a 1 GB fancy-index copy
             pixels = np.ascontiguousarray(image.reshape(-1, image.shape[-1]), dtype=np.float64)

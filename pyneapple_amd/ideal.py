@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-from .fitters import HipFitterBase
+from .fitters import HipFitterBase, validate_segmentation
 
 _INTERPOLATION_METHODS = ("linear", "cubic")
 
@@ -158,9 +158,7 @@ class HipIDEALFitter(HipFitterBase):
             dim_steps = self.dim_steps
         if segmentation is None:
             segmentation = np.ones(image.shape[:3], dtype=int)
-        segmentation = np.asarray(segmentation)
-        if segmentation.shape != image.shape[:3]:
-            raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {image.shape[:3]}.")
+        segmentation = validate_segmentation(segmentation, image.shape)
         seg4 = segmentation[..., np.newaxis]
         names = list(self.solver.model.param_names)
         n_params = len(names)
@@ -245,7 +243,11 @@ class HipIDEALFitter(HipFitterBase):
         # tensor.to() / tensor.cpu() -- 1.07 GB up and 1.05 GB down at C5
         img_d = api.upload(np.ascontiguousarray(image, np.float64), torch.empty(image.shape, dtype=torch.float64, device=dev),
                            dev_i, stream)
-        seg_d = torch.from_numpy(np.ascontiguousarray(segmentation, np.float64)).to(dev)  # ideal.py:309-310 casts the mask to float
+        # ideal.py:309-310: a mask that is not floating point is resized as float32 (and compared with the threshold in
+        # float32, like the host path above); the resize kernel works in fp64, its result is rounded to float32 before the test
+        seg_f32 = segmentation.dtype.kind != "f"
+        seg_d = torch.from_numpy(np.ascontiguousarray(segmentation, np.float64)).to(dev)
+        seg_thr = float(np.float32(self.segmentation_threshold)) if seg_f32 else float(self.segmentation_threshold)
         kw = dict(s._kernel_t1)
         self.step_params, self.stage_times_ = [], []
         prev = None  # (px, py, Z, n) device map of the previous level
@@ -267,7 +269,10 @@ class HipIDEALFitter(HipFitterBase):
             # fitted voxels of the level: resized segmentation above the threshold (ideal.py:199), all voxels when the ROI
             # does not survive the down-sampling (ideal.py:199-209) -- thresholding + stable compaction on the device
             idx_buf = torch.empty(n_all, dtype=torch.int64, device=dev)
-            n_sel = api.mask_select_device(resize(seg_d, Z), self.segmentation_threshold, idx_buf, dev_i, stream)
+            seg_l = resize(seg_d, Z)
+            if seg_f32 and seg_l is not seg_d:
+                seg_l = seg_l.to(torch.float32).to(torch.float64)
+            n_sel = api.mask_select_device(seg_l, seg_thr, idx_buf, dev_i, stream)
             all_px = n_sel == 0 or n_sel == n_all
             idx = None if all_px else idx_buf[:n_sel]
             n_px = n_all if all_px else n_sel
@@ -295,7 +300,8 @@ class HipIDEALFitter(HipFitterBase):
             nfev = torch.empty(n_px, dtype=torch.int32, device=dev)
             cost = torch.empty(n_px, dtype=torch.float64, device=dev)
             pcov = torch.empty((n_px, n, n), dtype=torch.float64, device=dev) if last else None
-            opts = api.make_opts(s._kernel_model, N, [], per_voxel, False, int(s.max_iter), float(s.tol), 1e-8, 1e-8,
+            opts = api.make_opts(s._kernel_model, N, [], per_voxel, False, int(s.max_iter), float(s.tol),
+                                 float(getattr(s, "xtol", 1e-8)), float(getattr(s, "gtol", 1e-8)),
                                  s.jacobian_mode, kw["t1_mode"], kw["tr"], kw["tm"])
             t_b = time.perf_counter()
             cost0 = None

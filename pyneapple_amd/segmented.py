@@ -17,7 +17,7 @@ from dataclasses import replace
 
 import numpy as np
 
-from .fitters import HipFitterBase, HipPixelWiseFitter, _accepts_pixel_fixed_params
+from .fitters import HipFitterBase, HipPixelWiseFitter, _accepts_pixel_fixed_params, validate_segmentation
 
 
 def _check_image(xdata, image):
@@ -162,10 +162,8 @@ class HipSegmentationWiseFitter(HipFitterBase):
             raise ValueError("segmentation is required for segmentation-wise fitting")
         t0 = time.perf_counter()
         xdata, image = _check_image(xdata, image)
-        segmentation = np.asarray(segmentation)
+        segmentation = validate_segmentation(segmentation, image.shape)
         spatial = image.shape[:-1]
-        if segmentation.shape != spatial:
-            raise ValueError(f"Segmentation shape {segmentation.shape} does not match expected image shape {spatial}.")
         self.n_measurements = len(xdata)
         self.image_shape = image.shape
         labels, inv = _label_positions(segmentation)

@@ -86,6 +86,15 @@ def _io_dtype(name):
     return np.float32 if name == "float32" else np.float64
 
 
+def _shard_device(first: int, k: int) -> int:
+    """Device of shard k.  PNX_SHARE_DEVICE=1 (rehearsal on a one-GPU box, used by the GPU tests) maps every shard to the
+    first device: the per-device host threads then run against one card, which is what the C ABI's thread-safety promise
+    (include/pnx.h) has to carry anyway."""
+    import os
+
+    return first if os.environ.get("PNX_SHARE_DEVICE") == "1" else first + k
+
+
 def _split(n: int, parts: int):
     edges = np.linspace(0, n, parts + 1).astype(np.int64)
     return [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
@@ -296,7 +305,7 @@ class HipCurveFitSolver(CurveFitBase):
             pv = (np.ascontiguousarray(p0[:, sl]), np.ascontiguousarray(lo[:, sl]),
                   np.ascontiguousarray(hi[:, sl])) if per_voxel else (p0, lo, hi)
             return api.curvefit(self._kernel_model, xdata, ydata[sl], *pv, fixed_vals=fv,
-                                device=self.device + k, **kw)
+                                device=_shard_device(self.device, k), **kw)
 
         with ThreadPoolExecutor(len(parts)) as ex:  # ctypes releases the GIL during the call
             outs = list(ex.map(work, range(len(parts))))
@@ -387,7 +396,7 @@ class HipNNLSSolver(NNLSBase):
             parts = _split(self.n_pixels, n_dev)
             with ThreadPoolExecutor(len(parts)) as ex:
                 outs = list(ex.map(lambda k: api.nnls(basis, reg, signal[parts[k][0]:parts[k][1]], max_iter,
-                                                      self.device + k), range(len(parts))))
+                                                      _shard_device(self.device, k)), range(len(parts))))
             res = {key: np.concatenate([o[key] for o in outs], axis=0) for key in outs[0]}
         status = res["status"]
         self.pixel_results_ = PixelResultsView(

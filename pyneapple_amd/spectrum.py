@@ -24,8 +24,16 @@ def find_spectrum_peaks_batch(spectra, bins, height: float = 0.1, regularized: b
 
 def find_spectrum_peaks(spectrum, bins, height: float = 0.1, regularized: bool = False):
     """One spectrum, the reference's signature and return shape (arrays of the detected peaks only)."""
-    d, f, n = find_spectrum_peaks_batch(np.asarray(spectrum, float)[None, :], bins, height, regularized, max_peaks=16)
-    k = min(int(n[0]), 16)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        d, f, n = find_spectrum_peaks_batch(np.asarray(spectrum, float)[None, :], bins, height, regularized,
+                                            max_peaks=api.SPECTRUM_MAX_PEAKS)
+    if int(n[0]) > api.SPECTRUM_MAX_PEAKS:
+        raise ValueError(f"the spectrum has {int(n[0])} peaks at height {height}; the device kernel keeps at most "
+                         f"{api.SPECTRUM_MAX_PEAKS} per voxel (raise `height`, or regularise the fit)")
+    k = int(n[0])
     return d[0, :k].copy(), f[0, :k].copy()
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the HIP curve-fit path against the oracle on unusual inputs (not collected by pytest:
-run it on a GPU box, `python tests/fuzz_gpu_vs_oracle.py [n_cases] [seed] [--hostile]`).  Every case draws a model, a b-value
+"""Differential fuzzing of the HIP curve-fit path against the oracle on unusual inputs (`python tests/fuzz_gpu_vs_oracle.py [n_cases] [seed] [--hostile] [--json out.json]` on a GPU box;
+tests/test_gpu_parity_large.py runs 100 fixed-seed cases of it in the GPU suite).  Every case draws a model, a b-value
 set (1..64 values, uniform or clinical or with duplicates), signal scale (1e-6..1e6), noise level, bounds (tight, loose,
 half infinite), start values (random inside the box, on a bound, equal to the truth), Jacobian mode, optional
 fixed parameters, optional T1 factor, small max_nfev.  Compared: status sign, cost (relative to the signal energy) and
@@ -158,21 +158,20 @@ def draw_case(rng):
 HOSTILE = "--hostile" in sys.argv
 
 
-def main():
-    if HOSTILE:
-        sys.argv.remove("--hostile")
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=300, seed=0, verbose=True, n_threads=8):
+    """n_cases random cases from `seed`; returns the summary dict that `--json` writes and the GPU suite asserts on."""
+    say = print if verbose else (lambda *a, **k: None)
+    rng = np.random.default_rng(seed)
     bad_cases = 0
-    tot_vox = tot_param_bad = tot_status_bad = tot_cost_bad = 0
+    tot_vox = tot_param_bad = tot_status_bad = tot_cost_bad = tot_sentinel_bad = 0
     for c in range(n_cases):
         desc, model, b, y, p0, lo, hi, kw = draw_case(rng)
         try:
-            o = oracle.curvefit(model, b, y, p0, lo, hi, n_threads=8, **kw)
+            o = oracle.curvefit(model, b, y, p0, lo, hi, n_threads=n_threads, **kw)
         except Exception as e:  # oracle rejects (e.g. m < n is fine, but some combos are invalid): the GPU must reject too
             try:
                 api.curvefit(model, b, y, p0, lo, hi, **kw)
-                print(f"[case {c}] oracle raised {e!r} but the GPU path did not: {desc}")
+                say(f"[case {c}] oracle raised {e!r} but the GPU path did not: {desc}")
                 bad_cases += 1
             except Exception:
                 pass
@@ -180,7 +179,7 @@ def main():
         try:
             r = api.curvefit(model, b, y, p0, lo, hi, **kw)
         except Exception as e:
-            print(f"[case {c}] GPU path raised {e!r}: {desc}")
+            say(f"[case {c}] GPU path raised {e!r}: {desc}")
             bad_cases += 1
             continue
         n_vox = y.shape[0]
@@ -197,20 +196,49 @@ def main():
         sentinel_bad = fail_same & ((r["popt"] != o["popt"]).any(axis=0) | (r["status"] != o["status"]))
         tot_vox += n_vox
         tot_status_bad += int(st_bad.sum()); tot_cost_bad += int(cost_bad.sum()); tot_param_bad += int(par_bad.sum())
+        tot_sentinel_bad += int(sentinel_bad.sum())
         n_bad = int(st_bad.sum() + cost_bad.sum() + sentinel_bad.sum())
         if n_bad or par_bad.sum():
             flag = "FAIL" if n_bad > 0.02 * n_vox + (1 if n_vox > 50 else 0) else "note"
-            print(f"[case {c}] {flag}: status {int(st_bad.sum())} cost {int(cost_bad.sum())} sentinel {int(sentinel_bad.sum())} "
-                  f"params {int(par_bad.sum())} of {n_vox}: {desc}")
+            say(f"[case {c}] {flag}: status {int(st_bad.sum())} cost {int(cost_bad.sum())} sentinel {int(sentinel_bad.sum())} "
+                f"params {int(par_bad.sum())} of {n_vox}: {desc}")
             if st_bad.any():
-                i = int(np.nonzero(st_bad)[0][0]); print(f"      voxel {i}: gpu status {r['status'][i]} nfev {r['nfev'][i]} cost {r['cost'][i]:.6g} | oracle status {o['status'][i]} nfev {o['nfev'][i]} cost {o['cost'][i]:.6g}")
+                i = int(np.nonzero(st_bad)[0][0]); say(f"      voxel {i}: gpu status {r['status'][i]} nfev {r['nfev'][i]} cost {r['cost'][i]:.6g} | oracle status {o['status'][i]} nfev {o['nfev'][i]} cost {o['cost'][i]:.6g}")
             elif cost_bad.any():
-                i = int(np.nonzero(cost_bad)[0][0]); print(f"      voxel {i}: gpu cost {r['cost'][i]:.10g} nfev {r['nfev'][i]} popt {r['popt'][:, i]} | oracle cost {o['cost'][i]:.10g} nfev {o['nfev'][i]} popt {o['popt'][:, i]}")
+                i = int(np.nonzero(cost_bad)[0][0]); say(f"      voxel {i}: gpu cost {r['cost'][i]:.10g} nfev {r['nfev'][i]} popt {r['popt'][:, i]} | oracle cost {o['cost'][i]:.10g} nfev {o['nfev'][i]} popt {o['popt'][:, i]}")
             if flag == "FAIL":
                 bad_cases += 1
-    print(f"{n_cases} cases, {tot_vox} voxels: status-sign disagreements {tot_status_bad}, cost disagreements {tot_cost_bad}, "
-          f"parameter-only disagreements on determined voxels {tot_param_bad}; failing cases {bad_cases}")
-    return 1 if bad_cases else 0
+    say(f"{n_cases} cases, {tot_vox} voxels: status-sign disagreements {tot_status_bad}, cost disagreements {tot_cost_bad}, "
+        f"parameter-only disagreements on determined voxels {tot_param_bad}; failing cases {bad_cases}")
+    from pyneapple_amd import _build
+
+    return {"fuzzer": "curvefit", "hostile": HOSTILE, "n_cases": n_cases, "seed": seed, "voxels": tot_vox,
+            "status_sign_disagreements": tot_status_bad, "cost_disagreements": tot_cost_bad,
+            "parameter_only_disagreements_on_determined_voxels": tot_param_bad, "sentinel_disagreements": tot_sentinel_bad,
+            "failing_cases": bad_cases,
+            "thresholds": {"cost": "1e-5 relative + 1e-9 of the signal energy", "parameters": "rtol 1e-4 where the oracle's pcov "
+                           "puts every standard deviation below 20 % of its parameter", "failing case": "status / cost / sentinel "
+                           "disagreements on more than 2 % of its voxels"},
+            "source_ids": _build.source_ids()}
+
+
+def main():
+    import json
+
+    if HOSTILE:
+        sys.argv.remove("--hostile")
+    out = None
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    res = run(n_cases, seed)
+    if out:
+        with open(out, "w") as fh:
+            json.dump(res, fh, indent=1)
+    return 1 if res["failing_cases"] else 0
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the HIP NNLS path against the oracle (run by hand on a GPU box:
-`python tests/fuzz_gpu_vs_oracle_nnls.py [n_cases] [seed]`).  Random number of measurements (3..64) and bins (4..256),
+"""Differential fuzzing of the HIP NNLS path against the oracle (`python tests/fuzz_gpu_vs_oracle_nnls.py [n_cases] [seed] [--json out.json]`
+on a GPU box; tests/test_gpu_parity_large.py runs 100 fixed-seed cases of it in the GPU suite).  Random number of measurements (3..64) and bins (4..256),
 D range, regulariser (none, orders 0-3, a dense random matrix), mu, signal scale 1e-6..1e6, noise, number of
 compartments, iteration limit (tiny, default, 0 = SciPy's 3 n).  With a regulariser of full column rank the minimiser
 is unique: coefficients are compared (1e-6 of the spectrum peak), as are status, rnorm and the iteration counts.
@@ -17,9 +17,10 @@ from oracle import pnx_oracle as oracle  # noqa: E402
 from pyneapple_amd import api  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=200, seed=0, verbose=True, n_threads=8):
+    """n_cases random cases from `seed`; returns the summary dict that `--json` writes and the GPU suite asserts on."""
+    print_ = print if verbose else (lambda *a, **k: None)
+    rng = np.random.default_rng(seed)
     bad = 0
     tot = coef_bad = stat_bad = iter_bad = rn_bad = 0
     for c in range(n_cases):
@@ -51,10 +52,10 @@ def main():
         try:
             r = api.nnls(basis, reg, y, max_iter)
         except Exception as e:
-            print(f"[case {c}] GPU raised {e!r}: {desc}")
+            print_(f"[case {c}] GPU raised {e!r}: {desc}")
             bad += 1
             continue
-        o = oracle.nnls(basis, reg, y, max_iter, n_threads=8)
+        o = oracle.nnls(basis, reg, y, max_iter, n_threads=n_threads)
         tot += n_vox
         sb = r["status"] != o["status"]
         ok = (r["status"] == 1) & (o["status"] == 1)
@@ -73,15 +74,40 @@ def main():
         stat_bad += int(sb.sum()); coef_bad += int(cb.sum()); rn_bad += int(rb.sum()); iter_bad += int(ib.sum())
         if sb.any() or cb.any() or rb.any() or neg or sent.any() or ib.sum() > 0.02 * n_vox + 1:
             hard = sb.any() or cb.any() or rb.any() or neg or sent.any()
-            print(f"[case {c}] {'FAIL' if hard else 'note'}: status {int(sb.sum())} coeff {int(cb.sum())} rnorm {int(rb.sum())} iters {int(ib.sum())} "
+            print_(f"[case {c}] {'FAIL' if hard else 'note'}: status {int(sb.sum())} coeff {int(cb.sum())} rnorm {int(rb.sum())} iters {int(ib.sum())} "
                   f"sentinel {int(sent.sum())} negative {bool(neg)} of {n_vox}: {desc}")
             if sb.any():
-                i = int(np.nonzero(sb)[0][0]); print(f"      voxel {i}: gpu status {r['status'][i]} iters {r['iters'][i]} | oracle {o['status'][i]} iters {o['iters'][i]}")
+                i = int(np.nonzero(sb)[0][0]); print_(f"      voxel {i}: gpu status {r['status'][i]} iters {r['iters'][i]} | oracle {o['status'][i]} iters {o['iters'][i]}")
             elif cb.any():
-                i = int(np.nonzero(cb)[0][0]); print(f"      voxel {i}: coeff err {ce[i]:.3g} of peak, iters gpu {r['iters'][i]} oracle {o['iters'][i]}, rnorm gpu {r['residual'][i]:.12g} oracle {o['residual'][i]:.12g}")
+                i = int(np.nonzero(cb)[0][0]); print_(f"      voxel {i}: coeff err {ce[i]:.3g} of peak, iters gpu {r['iters'][i]} oracle {o['iters'][i]}, rnorm gpu {r['residual'][i]:.12g} oracle {o['residual'][i]:.12g}")
             bad += bool(hard)
-    print(f"{n_cases} cases, {tot} voxels: status {stat_bad}, coefficients {coef_bad}, rnorm {rn_bad}, iteration-count {iter_bad} disagreements; failing cases {bad}")
-    return 1 if bad else 0
+    print_(f"{n_cases} cases, {tot} voxels: status {stat_bad}, coefficients {coef_bad}, rnorm {rn_bad}, iteration-count {iter_bad} disagreements; failing cases {bad}")
+    from pyneapple_amd import _build
+
+    return {"fuzzer": "nnls", "n_cases": n_cases, "seed": seed, "voxels": tot, "status_disagreements": stat_bad,
+            "coefficient_disagreements": coef_bad, "rnorm_disagreements": rn_bad, "iteration_count_disagreements": iter_bad,
+            "failing_cases": bad,
+            "thresholds": {"coefficients": "1e-6 of the spectrum peak (regularisers of full column rank)",
+                           "rnorm": "1e-8 relative + 1e-12 (1e-7 without regulariser) of the signal norm",
+                           "failing case": "any status / coefficient / rnorm / sentinel disagreement or a negative coefficient"},
+            "source_ids": _build.source_ids()}
+
+
+def main():
+    import json
+
+    out = None
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    res = run(n_cases, seed)
+    if out:
+        with open(out, "w") as fh:
+            json.dump(res, fh, indent=1)
+    return 1 if res["failing_cases"] else 0
 
 
 if __name__ == "__main__":

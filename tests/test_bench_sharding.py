@@ -33,6 +33,18 @@ def test_launcher_spawns_n_ranks_that_partition_one_volume():
     assert all(a["rows"][1] == b["rows"][0] for a, b in zip(ranks[:-1], ranks[1:]))
 
 
+def test_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that exits non-zero at start-up must not leave its peers waiting in the rendezvous until the backend's
+    timeout: the launcher polls all ranks, terminates the rest and returns the failing rank's code."""
+    import time
+
+    t = time.time()
+    r = _run(["--gpus", "3", "--launch-check", "--fail-rank", "2"], env={"PNX_BENCH_LAUNCH_HOLD": "60"})
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "rank 2 exited with code 3" in r.stderr
+    assert time.time() - t < 30  # not the 60 s the surviving ranks would have waited
+
+
 def test_gpus_flag_must_match_world_size():
     r = _run(["--gpus", "4", "--launch-check"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr

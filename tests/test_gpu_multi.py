@@ -1,0 +1,111 @@
+"""The multi-device code paths on ONE device (what a one-GPU box can put on hardware): concurrent calls through the C ABI
+from several host threads (include/pnx.h: "every entry point may be called from several host threads at once"), the
+plugin's n_gpus sharding (solvers.py: one host thread per device through the blocking ABI) with every shard mapped to
+device 0, and bench.py's N-rank flow as fresh child processes that share the card.  Mirrors the reference's own
+two-worker test (tests/test_solver_curvefit.py:931-952: n_pools=2 equals the serial result)."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _triexp(n_vox, seed=7):
+    from pyneapple_amd import synth
+
+    b, y, _ = synth.make_numpy("tri_reduced", n_vox, 32, sigma=0.01, seed=seed)
+    _, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    return b, y, p0, lo, hi
+
+
+def test_curvefit_abi_from_four_threads_equals_one_call(gpu):
+    n = 40000 + 37
+    b, y, p0, lo, hi = _triexp(n)
+    whole = gpu.curvefit("tri_reduced", b, y, p0, lo, hi)
+    cuts = [0, 9000, 20011, 31000, n]
+    with ThreadPoolExecutor(4) as ex:
+        parts = list(ex.map(lambda k: gpu.curvefit("tri_reduced", b, y[cuts[k]:cuts[k + 1]], p0, lo, hi), range(4)))
+    np.testing.assert_array_equal(np.concatenate([r["popt"] for r in parts], axis=1), whole["popt"])
+    np.testing.assert_array_equal(np.concatenate([r["pcov"] for r in parts], axis=0), whole["pcov"])
+    for k in ("status", "nfev", "cost"):
+        np.testing.assert_array_equal(np.concatenate([r[k] for r in parts]), whole[k])
+
+
+def test_nnls_abi_from_four_threads_equals_one_call(gpu):
+    from pyneapple_amd import synth
+
+    n = 6000 + 5
+    bins, basis, reg = synth.nnls_matrices(32)
+    _, y, _ = synth.make_numpy("tri_reduced", n, 32, sigma=0.01, scale=1000.0, seed=3)
+    whole = gpu.nnls(basis, reg, y, 250)
+    cuts = [0, 1500, 3001, 4700, n]
+    # a plan per thread (four plans, four kernels in flight on the card) ...
+    with ThreadPoolExecutor(4) as ex:
+        parts = list(ex.map(lambda k: gpu.nnls(basis, reg, y[cuts[k]:cuts[k + 1]], 250), range(4)))
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(np.concatenate([r[k] for r in parts], axis=0), whole[k])
+    # ... and ONE plan shared by four threads (its scratch serves one solve at a time: the plan's lock)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    with ThreadPoolExecutor(4) as ex:
+        parts = list(ex.map(lambda k: plan.solve(y[cuts[k]:cuts[k + 1]], 250), range(4)))
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(np.concatenate([r[k] for r in parts], axis=0), whole[k])
+
+
+def test_plugin_n_gpus_shards_equal_the_single_device_fit(gpu, monkeypatch):
+    from pyneapple_amd.models import NNLSModel, TriExpModel
+    from pyneapple_amd.solvers import HipCurveFitSolver, HipNNLSSolver
+    from pyneapple_amd import synth
+
+    monkeypatch.setenv("PNX_SHARE_DEVICE", "1")  # both shards on device 0 (the box has one)
+    b, y, p0, lo, hi = _triexp(12000 + 3)
+    names = list(synth.P0["tri_reduced"])
+    mk = lambda n: HipCurveFitSolver(model=TriExpModel(), max_iter=250, tol=1e-8, p0=dict(synth.P0["tri_reduced"]),
+                                     bounds=dict(synth.BOUNDS["tri_reduced"]), n_gpus=n)
+    one, two = mk(1).fit(b, y), mk(2).fit(b, y)
+    for nme in names:
+        np.testing.assert_array_equal(one.params_[nme], two.params_[nme])
+    np.testing.assert_array_equal(one.diagnostics_["pcov"], two.diagnostics_["pcov"])
+    np.testing.assert_array_equal(one.diagnostics_["status"], two.diagnostics_["status"])
+    # per-voxel start values and a per-voxel fixed parameter are split with the rows
+    rng = np.random.default_rng(0)
+    p0v = np.tile(p0[:, None], (1, y.shape[0])) * rng.uniform(0.95, 1.05, (5, y.shape[0]))
+    one, two = mk(1).fit(b, y, p0=p0v), mk(3).fit(b, y, p0=p0v)
+    for nme in names:
+        np.testing.assert_array_equal(one.params_[nme], two.params_[nme])
+
+    cfg = synth.NNLS_CFG
+    _, ys, _ = synth.make_numpy("tri_reduced", 3000 + 1, 32, sigma=0.01, scale=1000.0, seed=11)
+    mkn = lambda n: HipNNLSSolver(model=NNLSModel(d_range=cfg["d_range"], n_bins=cfg["n_bins"]), reg_order=cfg["reg_order"],
+                                  mu=cfg["mu"], max_iter=cfg["max_iter"], n_gpus=n)
+    one, two = mkn(1).fit(b, ys), mkn(2).fit(b, ys)
+    np.testing.assert_array_equal(one.params_["coefficients"], two.params_["coefficients"])
+    np.testing.assert_array_equal(one.diagnostics_["residual"], two.diagnostics_["residual"])
+    np.testing.assert_array_equal(one.diagnostics_["iters"], two.diagnostics_["iters"])
+
+
+def test_bench_two_ranks_as_child_processes_on_one_card():
+    """bench.py --gpus 2 end to end: the launcher spawns two fresh ranks before anything touches the GPU, both put their
+    shard on device 0 (PNX_BENCH_SHARE_GPU), gloo carries the barrier and the max-reduce (no second card for RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PNX_BENCH_SHARE_GPU="1", PNX_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--voxels", "262144", "--steps", "2",
+                        "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-host-mode"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2
+    assert d["config"]["voxels_per_rank"] == [131072, 131072] and d["config"]["voxels_total"] == 262144
+    assert d["check"]["converged_frac"] > 0.995
+    assert d["value"] > 0 and d["throughput"]["n_gpus"] == 2 and d["throughput"]["value"] > 0
+    assert d["pipelined"]["results_identical_across_buffers"] is True

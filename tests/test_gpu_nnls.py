@@ -90,6 +90,23 @@ def test_edge_shapes_and_failures(gpu, oracle):
         gpu.nnls(np.ones((4, 300)), None, np.ones((1, 4)))  # > 256 bins: refused, not silently wrong
 
 
+def test_unregularised_beyond_64_measurements_is_refused_not_switched(gpu):
+    """reg_order = 0 (the reference default, nnls_solver.py:37) with 65..128 measurements: the QR-form kernel keeps one
+    measurement per lane, and the Gram-form kernel selects other columns than SciPy on such ill conditioned bases
+    (DESIGN section 3): the plan is refused with PNX_ERR_UNSUPPORTED instead of quietly taking the other algorithm.
+    A well conditioned overdetermined basis (cond^2 far from 1 / eps) is what the Gram form is exact for, and stays."""
+    from pyneapple_amd import synth
+    from pyneapple_amd._lib import PnxError
+    b = np.linspace(0.0, 1200.0, 96)
+    bins = np.logspace(np.log10(0.0008), np.log10(0.5), 250)
+    basis = np.exp(-b[:, None] * bins[None, :])
+    with pytest.raises(PnxError) as e:
+        gpu.nnls(basis, np.zeros((250, 250)), np.ones((2, 96)), 250)
+    assert e.value.code == -2 and "64" in str(e.value)  # PNX_ERR_UNSUPPORTED
+    with pytest.raises(PnxError):
+        gpu.nnls(basis, None, np.ones((2, 96)), 250)
+
+
 def test_builders_on_device(gpu):
     d = load_golden("g4_nnls_250_r2")
     basis = gpu.nnls_basis(d["bvalues"], d["bins"])

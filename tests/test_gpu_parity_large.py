@@ -1,0 +1,58 @@
+"""A bounded slice of the large-sample evidence inside the GPU suite: 65 536 voxels of the C3 workload and 16 384 of the C4
+workload against the oracle (the full-size runs are profiles/parity_large.py -> profiles/r03_parity_large.json), and 100
+fixed-seed cases of each differential fuzzer (tests/fuzz_gpu_vs_oracle*.py -> profiles/r03_fuzz_*.json).  The thresholds are
+the recorded rates of those runs with a margin; what the rates mean is argued in DESIGN.md section 3."""
+from __future__ import annotations
+
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_c3_sample_against_the_oracle(gpu, oracle):
+    r = _load("profiles/parity_large.py", "parity_large").c3(1 << 16, verbose=False)
+    assert r["success_equal"] == 1.0           # 1 048 576-voxel run: 1.0
+    assert r["status_equal"] >= 0.999          # 0.9994
+    assert r["nfev_equal"] >= 0.998            # 0.9989
+    assert r["within_1e-4"] >= 0.997           # 0.99857; the rest are flat valleys:
+    assert r["cost_rel_diff_all_max"] <= 1e-4  # ... their costs agree (1.0e-5 over the large run)
+    assert r["median_rel"] < 1e-7
+    assert r["pcov_rel_max_where_params_agree_median"] < 1e-6
+
+
+def test_c4_sample_against_the_oracle(gpu, oracle):
+    r = _load("profiles/parity_large.py", "parity_large").c4(1 << 14, verbose=False)
+    # 131 072-voxel run: every status, iteration count and support identical
+    assert r["status_equal"] == 1.0 and r["iters_equal"] == 1.0 and r["support_equal"] == 1.0
+    assert r["coef_err_max"] < 1e-6 and r["rnorm_rel_max"] < 1e-12
+
+
+def test_curvefit_fuzz_100_cases(gpu, oracle):
+    r = _load("tests/fuzz_gpu_vs_oracle.py", "fuzz_curvefit").run(100, seed=20260504, verbose=False)
+    assert r["failing_cases"] == 0, r
+    assert r["voxels"] > 5000
+    # 800-case runs: 3-10 status-sign, 4-19 cost, 8-18 parameter-only disagreements in ~84 000 voxels
+    assert r["status_sign_disagreements"] <= 0.001 * r["voxels"] + 3, r
+    assert r["cost_disagreements"] <= 0.001 * r["voxels"] + 3, r
+    assert r["sentinel_disagreements"] == 0, r
+
+
+def test_nnls_fuzz_100_cases(gpu, oracle):
+    r = _load("tests/fuzz_gpu_vs_oracle_nnls.py", "fuzz_nnls").run(100, seed=20260504, verbose=False)
+    # 400-case runs: status 4-10, coefficients 0-10 (mu = 0.002 only), rnorm 0 in ~25 000 voxels; cases that fail there are
+    # single rank-deficient / cycling voxels, so the bound here is on counts, not on "no failing case"
+    assert r["voxels"] > 3000
+    assert r["status_disagreements"] <= 0.002 * r["voxels"] + 2, r
+    assert r["coefficient_disagreements"] <= 0.002 * r["voxels"] + 2, r
+    assert r["rnorm_disagreements"] <= 2, r

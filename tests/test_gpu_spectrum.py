@@ -104,3 +104,29 @@ def test_parameter_maps_on_device(gpu):
     s = gpu.scatter_maps(spec, idx, shape)
     assert s.shape == shape + (11,) and (s[~mask] == 0).all()
     np.testing.assert_array_equal(s[mask], spec.astype(np.float32))
+
+
+def test_more_peaks_than_the_table_holds_is_flagged_not_truncated(gpu):
+    """A spectrum with more than 16 local maxima above `height` (an unregularised, noisy fit at a low threshold): the rows of
+    that voxel are NaN and n_peaks reports the count -- never fractions normalised over the first 16 peaks only."""
+    import warnings
+
+    from pyneapple_amd import spectrum
+
+    bins = np.logspace(-3, 0, 250)
+    x = np.zeros((3, 250))
+    x[0, 10::12] = 1.0  # 20 isolated peaks
+    x[1, [30, 90]] = (1.0, 3.0)
+    x[2, 5:245:10] = np.linspace(1, 2, 24)  # 24 peaks
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d, f, n = spectrum.find_spectrum_peaks_batch(x, bins, height=0.1, max_peaks=16)
+        dc, fc = spectrum.apply_cutoffs_batch(x, bins, [(1e-3, 3e-2), (3e-2, 1.0)], height=0.1)
+    assert [int(v) for v in n] == [20, 2, 24] and any("more than 16 peaks" in str(m.message) for m in w)
+    assert np.isnan(d[0]).all() and np.isnan(f[0]).all() and np.isnan(d[2]).all() and np.isnan(dc[0]).all() and np.isnan(fc[2]).all()
+    np.testing.assert_allclose(f[1, :2], [0.25, 0.75])
+    assert np.isfinite(fc[1]).any()
+    with pytest.raises(ValueError, match="20 peaks"):
+        spectrum.find_spectrum_peaks(x[0], bins, height=0.1)
+    dd, ff = spectrum.find_spectrum_peaks(x[1], bins, height=0.1)
+    np.testing.assert_allclose(ff, [0.25, 0.75])

@@ -332,3 +332,30 @@ def test_bulk_copies_round_trip(gpu):
     np.testing.assert_array_equal(api.download(m, 0), np.arange(24.0).reshape(4, 6).T)
     with pytest.raises(ValueError):
         api.upload(np.zeros(3), torch.empty(4, dtype=torch.float64, device=dev), 0)
+
+
+@pytest.mark.gpu
+def test_device_pyramid_honours_the_solvers_xtol_gtol(gpu):
+    """The HBM-resident level loop builds its own option block: it must carry the solver's xtol / gtol like the host path
+    does (a coarse xtol stops every level's fit earlier, on both paths alike)."""
+    from pyneapple_amd.solvers import HipCurveFitSolver
+
+    rng = np.random.default_rng(5)
+    b = np.linspace(0, 1200, 24)
+    X, Y, Z = 16, 16, 1
+    f1 = 0.2 + 0.1 * rng.random((X, Y, Z))
+    img = f1[..., None] * np.exp(-b * 0.02) + (1 - f1[..., None]) * np.exp(-b * 0.001)
+    img = img * (1 + 0.02 * rng.standard_normal(img.shape))
+    steps = np.array([[4, 4], [16, 16]])
+    tol = {"f1": 0.5, "D1": 0.5, "D2": 0.5}
+
+    def run(resident, **kw):
+        solver = HipCurveFitSolver(model=BiExpModel(), max_iter=250, tol=1e-8, p0={"f1": 0.2, "D1": 0.01, "D2": 0.001},
+                                   bounds={"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}, **kw)
+        HipIDEALFitter(solver, steps, tol, device_resident=resident).fit(b, img)
+        return solver
+
+    coarse_h, coarse_d, fine_d = run(False, xtol=1e-2), run(True, xtol=1e-2), run(True)
+    np.testing.assert_array_equal(coarse_d.diagnostics_["nfev"], coarse_h.diagnostics_["nfev"])
+    np.testing.assert_allclose(coarse_d.params_["D1"], coarse_h.params_["D1"], rtol=1e-6)
+    assert coarse_d.diagnostics_["nfev"].mean() < fine_d.diagnostics_["nfev"].mean()  # the coarse tolerance was in force
