@@ -116,23 +116,30 @@ __device__ __forceinline__ double swap_add32(double v) {  // + the lane 32 away
 __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+// v_max_f64 as it is: fmax() puts a canonicalising v_max_f64 x, x, x in front of every operand (IEEE mode), three
+// instructions where one does -- the dual values are ordinary numbers or -inf, never signalling NaNs
+__device__ __forceinline__ double max1(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // maximum over the wave, in every lane
 __device__ __forceinline__ double allreduce_max(double v) {
-    v = fmax(v, dppx<0xB1>(v));
-    v = fmax(v, dppx<0x4E>(v));
-    v = fmax(v, dppx<0x141>(v));
-    v = fmax(v, dppx<0x128>(v));
+    v = max1(v, dppx<0xB1>(v));
+    v = max1(v, dppx<0x4E>(v));
+    v = max1(v, dppx<0x141>(v));
+    v = max1(v, dppx<0x128>(v));
     {
         const int lo = __double2loint(v), hi = __double2hiint(v);
         const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
         const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+        v = max1(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
     }
     {
         const int lo = __double2loint(v), hi = __double2hiint(v);
         const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
         const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+        v = max1(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
     }
     return v;
 }
@@ -198,9 +205,7 @@ __device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs,
     const double *xh = xs + h;
     const lds_int *ph = ps + h;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const int p2 = (p + 1) & ~1;  // rounded up to a pair: the pad entry holds x = 0, bin 0
-    int i = 0;
-    for (; i + 16 <= p2; i += 16) {
+    for (int i = 0; i < p; i += 16) {  // the staged arrays are zero padded to the end of the slot (a multiple of 16)
         double xv[8], bv[8];
         int jv[8];
 #pragma unroll
@@ -219,23 +224,6 @@ __device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs,
         a2 = fma(xv[6], bv[6], a2);
         a3 = fma(xv[7], bv[7], a3);
     }
-    if (i + 8 <= p2) {
-        double xv[4], bv[4];
-        int jv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            xv[u] = xh[i + 2 * u];
-            jv[u] = ph[i + 2 * u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = Bm[jv[u]];
-        a0 = fma(xv[0], bv[0], a0);
-        a1 = fma(xv[1], bv[1], a1);
-        a2 = fma(xv[2], bv[2], a2);
-        a3 = fma(xv[3], bv[3], a3);
-        i += 8;
-    }
-    for (; i < p2; i += 2) a0 = fma(xh[i], Bm[ph[i]], a0);
     return swap_add32((a0 + a1) + (a2 + a3));
 }
 // out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS.  Two groups of four rows (eight ds_read_b128
@@ -313,6 +301,16 @@ __device__ __forceinline__ int fresh(int lane) {
     return lane;
 }
 
+// The kernel arguments are read from the kernarg segment where they are needed (scalar loads), through a pointer the
+// optimiser cannot see through: kept in scalar registers for the whole kernel, the 9 pointers and 5 regulariser
+// coefficients push ~100 SGPRs into VGPR lanes, and every use costs a v_readlane -- a VALU instruction in a VALU-bound kernel.
+typedef const BlkArgs __attribute__((address_space(4))) KArgs;
+__device__ __forceinline__ KArgs *kargs() {
+    KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // per-voxel state that the phases below share
 struct VoxState {
     double q[kPS], x[kPS], z[kPS];  // by position
@@ -337,10 +335,10 @@ template <int NI> __device__ __forceinline__ void load_blocks(const double *Mg, 
 // One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
 // the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
 template <int NI>
-__device__ __forceinline__ bool try_append(const BlkArgs &A, double *Mg, const lds_int *ps, int lane, int la, int lb, int jmax,
+__device__ __forceinline__ bool try_append(const double *G, double *Mg, const lds_int *ps, int lane, int la, int lb, int jmax,
                                            double wj, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
-    const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
+    const double *grow = G + (size_t)jmax * kNnlsMaxBins;
     double blk[NI][NI];
     wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
     load_blocks<NI>(Mg, la, lb, blk);
@@ -526,7 +524,7 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
 
 constexpr int kBail = 2;  // internal status: the passive set wants more than kMaxPos columns, the general kernel redoes the voxel
 
-__global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A) {
+__global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) {  // read through kargs()
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -534,7 +532,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
     extern __shared__ double dyn_lds[];
     const int lane = threadIdx.x & (kW - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
+    const int n = kargs()->n_bins, nm = kargs()->n_meas, nreg = kargs()->n_reg;
     const int m_total = nm + nreg;
     double *Bl = dyn_lds;
     double *scr = dyn_lds + kBMeas * kBStride + wave * kScr;
@@ -542,20 +540,20 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
     lds_int *ps = reinterpret_cast<lds_int *>(scr + kMaxPos);          // [128] bin by position
     double *xbuf = scr + kMaxPos + kMaxPos / 2;                        // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
     double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
-    double *Mg = A.Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
+    double *Mg = kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
     for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
         const int m = e / kBStride, j = e - m * kBStride;
-        Bl[e] = (m < nm && j < kNnlsMaxBins) ? A.Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
+        Bl[e] = (m < nm && j < kNnlsMaxBins) ? kargs()->Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
     }
     __syncthreads();  // the only workgroup barrier: from here on the waves never meet again
 
     for (;;) {
-        unsigned long long vq = next_voxel(A.queue, lane);
+        unsigned long long vq = next_voxel(kargs()->queue, lane);
         vq = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vq >> 32)) << 32) |
              (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
-        if (vq >= (unsigned long long)A.n_vox) break;
+        if (vq >= (unsigned long long)kargs()->n_vox) break;
         const long long vox = (long long)vq;
-        const double *yv = A.y + (size_t)vox * nm;
+        const double *yv = kargs()->y + (size_t)vox * nm;
 
         // y by measurement: lanes 0 .. 31, duplicated in 32 .. 63
         const int ml = lane & 31;
@@ -590,7 +588,9 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 bt_times(Bl, rb, ld, w);
                 lds_order();
                 double u[kSlots];
-                reg_terms<true>(xbuf, A.rc, A.rhb, n, S.p, ld, S.x, S.pidx, u, nullptr);
+                KArgs *K = kargs();
+                const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
+                reg_terms<true>(xbuf, rc, K->rhb, n, S.p, ld, S.x, S.pidx, u, nullptr);
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
                     w[s] -= u[s];
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             bool accepted = false;
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
-                const double best = uni(allreduce_max(fmax(fmax(w[0], w[1]), fmax(w[2], w[3]))));
+                const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
                 if (!(best > 0)) break;  // KKT satisfied
                 // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
                 int jmax = kNone;
@@ -623,12 +623,13 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
                 }
                 const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
                 const int lc = fresh(lane);
+                const double *Gp = kargs()->G;
                 if (nI <= 2)
-                    accepted = try_append<2>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<2>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else if (nI <= 4)
-                    accepted = try_append<4>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<4>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else
-                    accepted = try_append<6>(A, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<6>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 if (accepted) break;
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             // ---- inner loop: keep the passive-set solution feasible
             for (;;) {
                 iteration += 1;
-                if (iteration == A.max_iter) {
+                if (iteration == kargs()->max_iter) {
                     status = 0;
                     break;
                 }
@@ -860,7 +861,9 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
         if (status == 1) {
             double tt = 0, dummy[kSlots];
             lds_order();
-            reg_terms<false>(xbuf, A.rc, A.rhb, n, S.p, lane, S.x, S.pidx, dummy, &tt);  // leaves x in bin order in xbuf
+            KArgs *K = kargs();
+            const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
+            reg_terms<false>(xbuf, rc, K->rhb, n, S.p, lane, S.x, S.pidx, dummy, &tt);  // leaves x in bin order in xbuf
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof(lane, s)];
             lds_order();
@@ -872,19 +875,22 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs A
             rn = sqrt(wave_sum(fma(r, r, tt)));
         } else
             rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
-        if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
-            if (lane == 0) A.bail[atomicAdd(A.n_bail, 1)] = (int32_t)vox;
-        } else {
-            double *cv = A.coeff + (size_t)vox * n;
+        {
+            KArgs *K = kargs();
+            if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
+                if (lane == 0) K->bail[atomicAdd(K->n_bail, 1)] = (int32_t)vox;
+            } else {
+                double *cv = K->coeff + (size_t)vox * n;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
-                const int j = binof(lane, s);
-                if (j < n) cv[j] = xb[s];
-            }
-            if (lane == 0) {
-                A.rnorm[vox] = rn;
-                if (A.status) A.status[vox] = (int8_t)status;
-                if (A.iters) A.iters[vox] = iteration;
+                for (int s = 0; s < kSlots; ++s) {
+                    const int j = binof(lane, s);
+                    if (j < n) cv[j] = xb[s];
+                }
+                if (lane == 0) {
+                    K->rnorm[vox] = rn;
+                    if (K->status) K->status[vox] = (int8_t)status;
+                    if (K->iters) K->iters[vox] = iteration;
+                }
             }
         }
         STAMP(8);
