@@ -534,8 +534,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = kargs()->n_bins, nm = kargs()->n_meas, nreg = kargs()->n_reg;
     const int m_total = nm + nreg;
-    double *Bl = dyn_lds;
-    double *scr = dyn_lds + kBMeas * kBStride + wave * kScr;
+    // the per-wave scratch comes first: its addresses then fit the 16-bit offset field of the DS instructions (behind the
+    // 66 KB of B every access needed a VALU add for its address: 18 of them per step of the B x loop alone)
+    double *scr = dyn_lds + wave * kScr;
+    double *Bl = dyn_lds + kBlkWaves * kScr;
     double *xs = scr;                                                  // [128] x by position
     lds_int *ps = reinterpret_cast<lds_int *>(scr + kMaxPos);          // [128] bin by position
     double *xbuf = scr + kMaxPos + kMaxPos / 2;                        // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
