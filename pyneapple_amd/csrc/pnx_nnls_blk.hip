@@ -709,6 +709,17 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             car[s] = (i < jj) ? Mg[CK(jbase + i, kMSlab, 10, jj)] : 0.0;
                         }
                     }
+                    // the first rows of the rotation sweep ride on the same round trip (their loads do not depend on the
+                    // coefficients computed below); rows < 64 only: one register per row and lane
+                    constexpr int kFirst = 12;
+                    const int e0 = (pp - 1) < kW ? (pp - 1) : kW;
+                    const int nfirst = e0 - jj < 0 ? 0 : (e0 - jj < kFirst ? e0 - jj : kFirst);
+                    double nx0[kFirst];
+#pragma unroll
+                    for (int r = 0; r < kFirst; ++r) {
+                        const int row = jj + r + 1 < pp ? jj + r + 1 : pp - 1;  // clamped: the surplus loads are not used
+                        nx0[r] = Mg[CK(moff(row) + (lane < jj ? lane : lane + 1), kMSlab, 16, row)];
+                    }
 #pragma unroll
                     for (int s = 0; s < kPS; ++s) {
                         pre[s] = carry;
@@ -778,9 +789,24 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             }
                         };
                         const int hi = pp - 1;
-                        {   // rows < 64: one register per row and lane, eight rows per step
+#pragma unroll
+                        for (int r = 0; r < kFirst; ++r) {  // the prefetched rows
+                            if (r >= nfirst) break;
+                            const int i = jj + r;
+                            const double c_ = rl(cs[0], i & 63), s_ = rl(sn[0], i & 63);
+                            const double qnx = rl(qsh[0], i & 63);
+                            if (lane <= i) {
+                                const double outv = c_ * car[0] - s_ * nx0[r];
+                                car[0] = s_ * car[0] + c_ * nx0[r];
+                                Mg[CK(moff(i) + lane, kMSlab, 17, i)] = outv;
+                            }
+                            const double oq = c_ * carq - s_ * qnx;
+                            carq = s_ * carq + c_ * qnx;
+                            if (lane == (i & 63)) S.q[0] = oq;
+                        }
+                        {   // further rows < 64: eight per step
                             const int e = hi < kW ? hi : kW;
-                            int i = jj;
+                            int i = jj + nfirst;
                             for (; i + 8 <= e; i += 8) rows(i, SlotTag<0>{}, SlotTag<8>{});
                             if (i + 4 <= e) {
                                 rows(i, SlotTag<0>{}, SlotTag<4>{});
