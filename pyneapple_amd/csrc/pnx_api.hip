@@ -507,7 +507,9 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
     }
 
     // ---- host staging: chunk ring (run_pipeline above)
-    const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", 3 << 18, 1024, 1 << 26);
+    // float32 transfers are half as long per voxel: a larger chunk (fewer drain tails of the persistent kernel) at the same
+    // exposed transfer latency -- C3 float32: 86.3 M voxels/s at 768 Ki, 89.8 M at 1 Mi, 82.5 M at 2 Mi (profiles/host_chunk_sweep_f32.py)
+    const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", F32 ? 1 << 20 : 3 << 18, 1024, 1 << 26);
     // chunk boundaries: with three or more full chunks the first and the last piece are a quarter chunk -- the first kernel
     // starts after a quarter of an upload, and the serial tail (last kernel, last download) is a quarter as long
     std::vector<size_t> bounds;
