@@ -43,9 +43,15 @@ constexpr int kRows2D = 48;                 // rows / columns of M handled block
 constexpr int kPS = 2;                      // register slots of a position-indexed vector: positions < 128
 constexpr int kMaxPos = kPS * kW;           // a voxel whose passive set wants to grow beyond that is handed to pnx_nnls.hip
 constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
-// per-wave LDS scratch, in doubles: xs[128] x by position | ps[128] (ints) bin by position | xbuf[264] x by bin with halo
-// (also the staging buffer of the M sweeps) | rb[32] residual of the measurements
-constexpr int kScr = kMaxPos + kMaxPos / 2 + kXbuf + 32;
+// per-wave LDS scratch, in doubles: ps[128] (ints) bin by position | xbuf[264] x by bin with halo.  xbuf is also the staging
+// buffer of the M sweeps, and -- in the part of the dual that runs before the stencil -- holds xs[128] (x by position) and
+// rb[32] (residual of the measurements): every LDS byte not spent here keeps a row of M on the chip
+constexpr int kScr = kMaxPos / 2 + kXbuf;
+#ifndef PNX_BLK_LDS_ROWS
+#define PNX_BLK_LDS_ROWS 32
+#endif
+constexpr int kLdsM = PNX_BLK_LDS_ROWS;     // rows of M that live in LDS (whole block rows): what every voxel uses all the time
+constexpr int kLdsMDoubles = (kLdsM / 8 + 1) * (32 * (kLdsM / 8));  // moff(kLdsM)
 constexpr int kMSlab = 32 * 16 * 17 + 64;   // doubles of M per wave: moff(128) = 32 I (I + 1) at I = 16, plus the overrun of a 64-lane row read
 typedef int __attribute__((may_alias)) lds_int;
 
@@ -91,6 +97,21 @@ __host__ __device__ constexpr int moff(int i) {
 }
 
 static_assert(kMSlab >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
+static_assert(kLdsMDoubles == moff(kLdsM) && kLdsM % 8 == 0, "LDS part of M: whole block rows");
+
+// M of one wave: rows < kLdsM in LDS, the others in the wave's global slab (same offsets moff(i) + k in both).  A row index
+// that is wave uniform picks its memory with a scalar branch.
+struct MRef {
+    double *l;  // LDS, kLdsMDoubles
+    double *g;  // global slab, kMSlab
+    __device__ __forceinline__ double ld(int row, int idx) const { return row < kLdsM ? l[idx] : g[CK(idx, kMSlab, 20, row)]; }
+    __device__ __forceinline__ void st(int row, int idx, double v) const {
+        if (row < kLdsM)
+            l[idx] = v;
+        else
+            g[CK(idx, kMSlab, 21, row)] = v;
+    }
+};
 
 // ---- reductions over one axis of the 8 x 8 lane grid (every lane of the group gets the sum) ----------------
 // a DPP lane permutation (every lane has a source): no `old` operand, so no register copy in front of the move
@@ -320,12 +341,12 @@ struct VoxState {
 };
 
 // blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
-template <int NI> __device__ __forceinline__ void load_blocks(const double *Mg, int la, int lb, double (&blk)[NI][NI]) {
+template <int NI> __device__ __forceinline__ void load_blocks(const MRef &M, int la, int lb, double (&blk)[NI][NI]) {
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
+    for (int I = NI - 1; I >= 0; --I) {  // the global block rows first: their loads have the longer way
         const int base = (I + 1) * (32 * I + 8 * la) + lb;
 #pragma unroll
-        for (int K = 0; K <= I; ++K) blk[I][K] = Mg[CK(base + 8 * K, kMSlab, 1, I)];
+        for (int K = 0; K <= I; ++K) blk[I][K] = 8 * I < kLdsM ? M.l[base + 8 * K] : M.g[CK(base + 8 * K, kMSlab, 1, I)];
     }
 }
 
@@ -335,13 +356,13 @@ template <int NI> __device__ __forceinline__ void load_blocks(const double *Mg, 
 // One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
 // the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
 template <int NI>
-__device__ __forceinline__ bool try_append(const double *G, double *Mg, const lds_int *ps, int lane, int la, int lb, int jmax,
+__device__ __forceinline__ bool try_append(const double *G, const MRef &M, const lds_int *ps, int lane, int la, int lb, int jmax,
                                            double wj, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const double *grow = G + (size_t)jmax * kNnlsMaxBins;
     double blk[NI][NI];
     wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
-    load_blocks<NI>(Mg, la, lb, blk);
+    load_blocks<NI>(M, la, lb, blk);
     const double Gjj = uni(grow[CK(jmax, kNnlsMaxBins, 2, p)]);
     // g in column layout: lane (a, b) holds g_{8 K + b}
     double gc[NI];
@@ -359,7 +380,9 @@ __device__ __forceinline__ bool try_append(const double *G, double *Mg, const ld
         double acc = 0;
 #pragma unroll
         for (int K = 0; K <= I; ++K) acc = fma(blk[I][K], gc[K], acc);
-        const double lr = allreduce_b(acc);  // l_{8 I + a}, the same in the lanes (a, *); rows >= p of M are zero
+        double lr = allreduce_b(acc);  // l_{8 I + a}, the same in the lanes (a, *)
+        // rows >= p: zero in the LDS part of M (kept so: no mask); in the global part they may hold a previous voxel's values
+        if (8 * I >= kLdsM) lr = (8 * I + la < p) ? lr : 0.0;
         ll = fma(lr, lr, ll);
 #pragma unroll
         for (int K = 0; K <= I; ++K) rK[K] = fma(blk[I][K], lr, rK[K]);
@@ -379,7 +402,7 @@ __device__ __forceinline__ bool try_append(const double *G, double *Mg, const ld
 #pragma unroll
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
-                m[s] = (k <= i) ? Mg[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end: masked
+                m[s] = (k <= i) ? M.g[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end: masked
                 part = fma(m[s], g[s], part);
             }
             const double li = wave_sum(part);
@@ -395,7 +418,7 @@ __device__ __forceinline__ bool try_append(const double *G, double *Mg, const ld
             for (int r = 0; r < 4; ++r) {
                 const int rbase = moff(i + r);
 #pragma unroll
-                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
+                for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
             }
             double part[4];
 #pragma unroll
@@ -443,7 +466,7 @@ __device__ __forceinline__ bool try_append(const double *G, double *Mg, const ld
 #pragma unroll
         for (int s = 0; s < kPS; ++s) {
             const int k = lane + kW * s;
-            if ((s == 0 || p >= kW) && k < width) Mg[CK(pbase + k, kMSlab, 8, p)] = k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0);
+            if ((s == 0 || p >= kW) && k < width) M.st(p, pbase + k, k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0));
         }
     }
     // the rank-one update of the solution
@@ -468,17 +491,20 @@ __device__ __forceinline__ bool try_append(const double *G, double *Mg, const ld
 
 // z = M^T q
 template <int NI>
-__device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, int la, int lb, VoxState &S) {
+__device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane, int la, int lb, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     double blk[NI][NI];
     wave_sync();
-    load_blocks<NI>(Mg, la, lb, blk);
+    load_blocks<NI>(M, la, lb, blk);
     lds_order();
     stg[lane] = S.q[0];
     lds_order();
     double qr[NI];
 #pragma unroll
-    for (int I = 0; I < NI; ++I) qr[I] = stg[8 * I + la];  // rows >= p of M are zero: what q holds there does not matter
+    for (int I = 0; I < NI; ++I) {  // LDS rows >= p of M are zero: what q holds there does not matter; global rows are masked
+        qr[I] = stg[8 * I + la];
+        if (8 * I >= kLdsM) qr[I] = (8 * I + la < p) ? qr[I] : 0.0;
+    }
     lds_order();
     double zK[NI];
 #pragma unroll
@@ -498,7 +524,7 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
 #pragma unroll
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
-                const double m0 = Mg[CK(rbase + k, kMSlab, 5, i)];
+                const double m0 = M.g[CK(rbase + k, kMSlab, 5, i)];
                 S.z[s] += a * ((k <= i) ? m0 : 0.0);
             }
         };
@@ -509,7 +535,7 @@ __device__ __forceinline__ void mt_times_q(double *Mg, double *stg, int lane, in
             for (int r = 0; r < 4; ++r) {
                 const int rbase = moff(i + r);
 #pragma unroll
-                for (int s = 0; s <= si; ++s) m[r][s] = Mg[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
+                for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -538,11 +564,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     // 66 KB of B every access needed a VALU add for its address: 18 of them per step of the B x loop alone)
     double *scr = dyn_lds + wave * kScr;
     double *Bl = dyn_lds + kBlkWaves * kScr;
-    double *xs = scr;                                                  // [128] x by position
-    lds_int *ps = reinterpret_cast<lds_int *>(scr + kMaxPos);          // [128] bin by position
-    double *xbuf = scr + kMaxPos + kMaxPos / 2;                        // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
-    double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
-    double *Mg = kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
+    lds_int *ps = reinterpret_cast<lds_int *>(scr);                    // [128] bin by position
+    double *xbuf = scr + kMaxPos / 2;                                  // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
+    double *xs = xbuf;                                                 // [128] x by position: dead before the stencil fills xbuf
+    double *rb = xbuf + kMaxPos;                                       // [32] residual of the measurements: likewise
+    MRef M;
+    M.g = kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
+    M.l = dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles;
+    for (int e = lane; e < kLdsMDoubles; e += kW) M.l[e] = 0.0;  // rows >= p of M are zero, from the first voxel on
     for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
         const int m = e / kBStride, j = e - m * kBStride;
         Bl[e] = (m < nm && j < kNnlsMaxBins) ? kargs()->Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
@@ -627,11 +656,11 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                 const int lc = fresh(lane);
                 const double *Gp = kargs()->G;
                 if (nI <= 2)
-                    accepted = try_append<2>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<2>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else if (nI <= 4)
-                    accepted = try_append<4>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<4>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 else
-                    accepted = try_append<6>(Gp, Mg, ps, lc, lc >> 3, lc & 7, jmax, best, S);
+                    accepted = try_append<6>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 if (accepted) break;
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
@@ -705,8 +734,8 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
                         for (int s = 0; s < kPS; ++s) {  // column jj (rows jj ..) and row jj (columns < jj): both reads in flight
                             const int i = lane + kW * s;
-                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? Mg[CK(moff(i) + jj, kMSlab, 9, i)] : 0.0;
-                            car[s] = (i < jj) ? Mg[CK(jbase + i, kMSlab, 10, jj)] : 0.0;
+                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? (i < kLdsM ? M.l[i < kLdsM ? moff(i) + jj : 0] : M.g[CK(moff(i) + jj, kMSlab, 9, i)]) : 0.0;
+                            car[s] = (i < jj) ? M.ld(jj, jbase + i) : 0.0;
                         }
                     }
                     // the first rows of the rotation sweep ride on the same round trip (their loads do not depend on the
@@ -718,7 +747,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
                     for (int r = 0; r < kFirst; ++r) {
                         const int row = jj + r + 1 < pp ? jj + r + 1 : pp - 1;  // clamped: the surplus loads are not used
-                        nx0[r] = Mg[CK(moff(row) + (lane < jj ? lane : lane + 1), kMSlab, 16, row)];
+                        nx0[r] = M.ld(row, moff(row) + (lane < jj ? lane : lane + 1));
                     }
 #pragma unroll
                     for (int s = 0; s < kPS; ++s) {
@@ -766,7 +795,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
                                 for (int s = 0; s <= si; ++s) {
                                     const int c = lane + kW * s;
-                                    nx[r][s] = Mg[CK(nbase + (c < jj ? c : c + 1), kMSlab, 13, i + r)];
+                                    nx[r][s] = M.ld(i + r + 1, nbase + (c < jj ? c : c + 1));
                                 }
                             }
 #pragma unroll
@@ -780,7 +809,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                                     if (c <= i + r) {
                                         const double outv = c_ * car[s] - s_ * nx[r][s];
                                         car[s] = s_ * car[s] + c_ * nx[r][s];
-                                        Mg[CK(obase + c, kMSlab, 14, i + r)] = outv;
+                                        M.st(i + r, obase + c, outv);
                                     }
                                 }
                                 const double oq = c_ * carq - s_ * qnx;
@@ -798,7 +827,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             if (lane <= i) {
                                 const double outv = c_ * car[0] - s_ * nx0[r];
                                 car[0] = s_ * car[0] + c_ * nx0[r];
-                                Mg[CK(moff(i) + lane, kMSlab, 17, i)] = outv;
+                                M.st(i, moff(i) + lane, outv);
                             }
                             const double oq = c_ * carq - s_ * qnx;
                             carq = s_ * carq + c_ * qnx;
@@ -838,12 +867,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                         for (int s = 0; s < kSlots; ++s)
                             if (binof(lane, s) == bin_out) S.inP[s] = false;
                     }
-                    {   // the vacated last row: rows >= p of M stay zero (the block sweeps carry no row masks)
+                    if (pp - 1 < kLdsM) {  // the vacated last row: LDS rows >= p of M stay zero (the block sweeps mask global rows only)
                         const int vbase = moff(pp - 1);
                         const int width = 8 * (((pp - 1) >> 3) + 1);
 #pragma unroll
                         for (int s = 0; s < kPS; ++s)
-                            if (lane + kW * s < width) Mg[CK(vbase + lane + kW * s, kMSlab, 15, pp)] = 0.0;
+                            if (lane + kW * s < width) M.st(pp - 1, vbase + lane + kW * s, 0.0);
                     }
                     S.p = pp - 1;
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
@@ -863,24 +892,23 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     const int nI = (S.p + 7) >> 3;
                     const int lm = fresh(lane);
                     if (nI <= 2)
-                        mt_times_q<2>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
+                        mt_times_q<2>(M, xbuf, lm, lm >> 3, lm & 7, S);
                     else if (nI <= 4)
-                        mt_times_q<4>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
+                        mt_times_q<4>(M, xbuf, lm, lm >> 3, lm & 7, S);
                     else
-                        mt_times_q<6>(Mg, xbuf, lm, lm >> 3, lm & 7, S);
+                        mt_times_q<6>(M, xbuf, lm, lm >> 3, lm & 7, S);
                 }
                 STAMP(6);
             }
         }
         STAMP(7);
 
-        // ---- the next voxel starts from an all-zero M
+        // ---- the next voxel starts from an all-zero LDS part of M
         {
-            const int pe = __builtin_amdgcn_readfirstlane(S.p);
-            for (int i = 0; i < pe; ++i) {
+            const int pe = __builtin_amdgcn_readfirstlane(S.p) < kLdsM ? __builtin_amdgcn_readfirstlane(S.p) : kLdsM;
+            for (int i = 0; i < pe; ++i) {  // the LDS rows only (kLdsM <= 64: one register slot)
                 const int width = 8 * ((i >> 3) + 1);
-                if (lane < width) Mg[moff(i) + lane] = 0.0;
-                if (i >= kW && lane + kW < width) Mg[moff(i) + lane + kW] = 0.0;
+                if (lane < width) M.l[moff(i) + lane] = 0.0;
             }
         }
         // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
@@ -935,7 +963,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-static size_t blk_lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * kScr); }
+static size_t blk_lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * (kScr + kLdsMDoubles)); }
 
 bool nnls_blk_applicable(const NnlsPlanData *P) {
     return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && !getenv("PNX_NNLS_NO_BLK");
