@@ -29,6 +29,7 @@ struct NnlsPlanData {
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
     int blk_groups = 0;       // its persistent workgroups (16 waves each)
     int32_t *blk_bail = nullptr;  // [0]: number of voxels the block kernel handed to the general one (more than 128 passive bins), [1 ..]: their indices
+    size_t blk_bail_cap = 0;      // voxels the list can hold
     unsigned long long *queue = nullptr;
 };
 

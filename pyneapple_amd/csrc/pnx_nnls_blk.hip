@@ -65,7 +65,8 @@ struct BlkArgs {
     const double *Bp;  // (n_meas, 256) zero padded
     double *Mglob;     // kMSlab doubles per wave, zero initialised (so that every block a sweep touches is finite)
     int32_t *n_bail;   // number of voxels handed over to the general kernel ...
-    int32_t *bail;     // ... and their indices
+    int32_t *bail;     // ... and their indices (within the call: vox_base + index within the chunk)
+    long long vox_base;  // first voxel of this launch within the call
     unsigned long long *queue;
     long long n_vox;
     int n_meas, n_bins, n_reg, max_iter;
@@ -934,7 +935,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         {
             KArgs *K = kargs();
             if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
-                if (lane == 0) K->bail[atomicAdd(K->n_bail, 1)] = (int32_t)vox;
+                if (lane == 0) K->bail[atomicAdd(K->n_bail, 1)] = (int32_t)(K->vox_base + vox);
             } else {
                 double *cv = K->coeff + (size_t)vox * n;
 #pragma unroll
@@ -980,14 +981,23 @@ int nnls_blk_plan_init(NnlsPlanData *P) {
     const size_t bytes = (size_t)P->blk_groups * kBlkWaves * kMSlab * sizeof(double);
     PNX_HIPB(hipMalloc(&P->Mblk, bytes));
     PNX_HIPB(hipMemset(P->Mblk, 0, bytes));
-    PNX_HIPB(hipMalloc(&P->blk_bail, (1 + (size_t)kAtyChunk) * sizeof(int32_t)));  // [0]: count, [1 ..]: voxel indices
-    PNX_HIPB(hipMemset(P->blk_bail, 0, sizeof(int32_t)));
+    P->blk_bail_cap = (size_t)kAtyChunk;
+    PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));  // [0]: count, [1 ..]: voxel indices
     return PNX_OK;
 }
 
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                           int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
-    // chunks of kAtyChunk voxels: the list of handed-over voxels is sized for one chunk
+    if (n_vox <= 0) return PNX_OK;
+    if (n_vox >= (int64_t)1 << 31) return set_error(PNX_ERR_INVALID, "n_vox=%lld: at most 2^31 - 1 voxels per call", (long long)n_vox);
+    if ((size_t)n_vox > P->blk_bail_cap) {  // the hand-over list holds every voxel of a call in the worst case
+        (void)hipFree(P->blk_bail);  // synchronises: no earlier solve of this plan is still using it
+        P->blk_bail = nullptr;
+        P->blk_bail_cap = (size_t)n_vox;
+        PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
+    }
+    PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
+    // launches of kAtyChunk voxels (256 per resident wave keep the drain tail small)
     for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
         const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
         BlkArgs a;
@@ -1001,6 +1011,7 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         a.Mglob = P->Mblk;
         a.n_bail = P->blk_bail;
         a.bail = P->blk_bail + 1;
+        a.vox_base = off;
         a.queue = P->queue;
         a.n_vox = c;
         a.n_meas = P->n_meas;
@@ -1010,16 +1021,14 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
         a.rhb = P->rhb;
         PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-        PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
         long long grid = (c + kBlkWaves - 1) / kBlkWaves;
         if (grid > P->blk_groups) grid = P->blk_groups;
         hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
         PNX_HIPB(hipGetLastError());
-        // voxels whose passive set outgrew this kernel (a few in 10^4 on the reference workload): the general kernel, from scratch
-        const int rc = nnls_redo_device(P, c, a.y, max_iter, a.coeff, a.rnorm, a.status, a.iters, P->blk_bail + 1, P->blk_bail, stream);
-        if (rc != PNX_OK) return rc;
     }
-    return PNX_OK;
+    // voxels whose passive set outgrew this kernel (about one in 10^4 on the reference workload, and the slowest ones: a single
+    // launch for the whole call, so that their long solves overlap): the general kernel, from scratch
+    return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk_bail + 1, P->blk_bail, stream);
 }
 
 }  // namespace pnx
