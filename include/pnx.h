@@ -148,6 +148,14 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  * NNLS plan: everything that is shared by all voxels of one fit -- the regularised design matrix
  * A = [basis; reg] (nnls_solver.py:61-73) -- is uploaded and factored into its Gram form once.
  *   basis (n_meas, n_bins) row-major host;  reg (n_reg, n_bins) row-major host or NULL (n_reg = 0).
+ * The plan picks the kernel; all of them walk the Lawson-Hanson path of scipy.optimize.nnls (same iteration counts):
+ *   - reg = one of the reference's banded matrices (model_functions/nnls.py:46-85, orders 1-3) and n_meas <= 32 (every
+ *     configuration the reference ships): basis resident in LDS, residual-form dual (csrc/pnx_nnls_blk.hip);
+ *   - no regulariser / an all-zero one (reg_order = 0, the reference default) and n_meas <= 64: QR form (pnx_nnls_qr.hip);
+ *     with n_meas > 64 the plan is REFUSED (PNX_ERR_UNSUPPORTED) unless the basis is well conditioned
+ *     (cond(basis)^2 < ~1e10, n_meas >= n_bins): the normal-equation kernel would pick other columns than SciPy on a
+ *     rank-deficient basis, and this library never changes the algorithm silently;
+ *   - anything else (dense regularisers, 33..128 measurements): Gram form (pnx_nnls.hip).
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;
 int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
@@ -198,7 +206,8 @@ int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg
  *     (log10 of the weighted geometric mean position -- the reference's own convention -- and the summed fraction);
  *     fractions renormalised over the ranges.
  *   spectrum (n_vox, n_bins) host|device; bins (n_bins,) host; cutoffs (n_cut, 2) host.
- *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks; the first max_peaks <= 16 are reported);
+ *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks: the first max_peaks <= 16 are reported; a spectrum with more
+ *     than 16 peaks gets NaN rows -- its fractions would have to be normalised over peaks the table cannot hold);
  *   d_values / f_values (n_vox, max_peaks) NaN padded; d_cut / f_cut (n_vox, n_cut <= 8).  Outputs host|device as `mem`.
  */
 int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectrum, const double *bins_host, double height,

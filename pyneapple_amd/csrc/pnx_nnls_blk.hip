@@ -8,19 +8,26 @@
 // Why a second kernel.  pnx_nnls.hip keeps every unit of a CU 55-70 % busy at once: the vector L1 (the dual
 // w = A^T y - G[:,P] x streams p rows of G = 2 KB each per outer iteration: 87 k L1 accesses per voxel), the VALU and the
 // scalar unit (one dependent LDS round trip and ~8 instructions per row of the inverse factor M, four sweeps over M per
-// iteration).  This kernel removes both loads:
-//   * THE BASIS LIVES IN LDS, ONCE PER CU (32 x 258 doubles = 66 KB, shared by the 16 waves of the only workgroup a CU
+// iteration).  This kernel takes both loads away:
+//   * THE BASIS LIVES IN LDS, ONCE PER CU (32 x 258 doubles = 66 KB, shared by the 12 waves of the only workgroup a CU
 //     holds).  The dual is evaluated in residual form, w = B^T (y - B_P x_P) - R^T (R x): p column gathers and 32 row
-//     reads out of LDS plus two 5-point stencils -- no row of G is read at all (G is only gathered: p numbers per
-//     candidate column), and the cancellation-free residual form is the more accurate one.  A^T y is never formed, so
-//     the MFMA Gram step and its 2 KB per voxel round trip through HBM are not part of this path.
+//     reads out of LDS plus two stencils -- no row of G is read at all (G is only gathered: p numbers per candidate
+//     column), and the cancellation-free residual form is the more accurate one.  A^T y is never formed, so the MFMA
+//     Gram step and its 2 KB per voxel round trip through HBM are not part of this path.
 //   * M = L^-1 IS DISTRIBUTED IN 8 x 8 BLOCKS OVER THE WAVE.  Lane (a, b) = (lane >> 3, lane & 7) owns element
-//     (8 I + a, 8 K + b) of block (I, K).  A product with M or M^T is then one FMA per block and lane (21 for 48 rows)
-//     and a three-step butterfly per block row / column (DPP within 16 lanes, v_permlane16/32_swap across), with all
-//     block loads in flight together -- instead of p dependent row steps.  M lives in a per-wave global slab (L2), rows
-//     padded to multiples of 8 so that block reads are whole 64-byte lines and row accesses stay contiguous; both
-//     sweeps of an append (l = M g, then l^T M) use the same register copy of the blocks.  Rows >= 48 (and the Givens
-//     sweep of a removal) go through the slab row by row with the loads of four rows in flight.
+//     (8 I + a, 8 K + b) of block (I, K).  l = M g is one FMA per block and lane (21 for 48 rows) and a three-step DPP
+//     butterfly per block row; the blocks are consumed row by row, each row's l going straight into the column sums of
+//     l^T M, which a reduce-scatter (v_permlane32 / 16_swap, two block columns per swap) delivers in position order.
+//     All block loads of a sweep are in flight together -- instead of p dependent row steps.  Rows < 32 of M live in
+//     LDS, the others in a per-wave global slab (rows padded to multiples of 8: a block read is whole 64-byte lines,
+//     a row access is contiguous); rows >= 48 and the Givens sweep of a removal go row by row with the loads of 4 - 12
+//     rows in flight.  Position-indexed vectors hold 128 positions (two register slots): a voxel whose passive set wants
+//     to grow beyond that (about one in 10^4 on the reference workload) is handed to pnx_nnls.hip through a list.
+// What bounds it (profiles/r03_*): VALU issue -- 64 k instructions per voxel at ~4.2 cycles, the SIMDs 76 % busy at three
+// waves each -- and the latency of what a wave does in sequence; every fp64 FMA of the B^T r product (128 per lane and
+// outer iteration) is needed, so the remaining lever is the instruction count around them.  The kernel arguments are read
+// from the kernarg segment where they are used, the LDS scratch sits below 64 KB (DS offsets as immediates), phases take
+// a fresh copy of the lane id: all three keep hoisted values out of registers the hot loops need.
 // One wavefront owns one voxel; waves pull voxels from an atomic queue and never meet after the basis is staged.
 #include <hip/hip_runtime.h>
 
@@ -390,7 +397,6 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     }
     ll = allreduce_a(ll);
     // rows >= 48: row by row (lanes over the columns), four rows in flight
-    double lcan[kPS] = {0, 0};  // l by position, rows >= 48 only
     double a1[kPS] = {0, 0};    // l^T M by position
     if (NI == 6 && p > kRows2D) {
         double g[kPS];
@@ -407,7 +413,6 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
                 part = fma(m[s], g[s], part);
             }
             const double li = wave_sum(part);
-            if (lane == (i & 63)) lcan[si] = li;
             ll = fma(li, li, ll);
 #pragma unroll
             for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[s], a1[s]);
@@ -434,7 +439,6 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double li = wave_sum(part[r]);
-                if (lane == ((i + r) & 63)) lcan[si] = li;
                 ll = fma(li, li, ll);
 #pragma unroll
                 for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[r][s], a1[s]);
