@@ -222,7 +222,7 @@ class CurvefitLeg:
         d2h = sum(a.nbytes for a in r.values() if a is not None)
         same = bool((self.torch.from_numpy(r["popt"]).to(self.popt.device) == self.popt).all().item())
         return {"workload": "same volume, host (numpy) arrays in and out through PNX_MEM_HOST", "value": self.n_vox / dt,
-                "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes), "d2h_bytes": int(d2h),
+                "unit": "voxels/s", "ms_per_step": dt * 1e3, "ms_reps": [t * 1e3 for t in ts], "h2d_bytes": int(y.nbytes), "d2h_bytes": int(d2h),
                 "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps, "equals_device_resident_result": same}
 
     def host_mode_f32(self, reps=2):
@@ -503,8 +503,8 @@ def sweep_roofline(device, torch, n_vox_override=0, reps=300):
     # the same launches back to back under one event pair: the figure rocprofv3's per-kernel average agrees with
     # (an event pair per launch adds ~25 us of marker serialisation to a 0.24 ms kernel)
     # three bursts of reps / 3 launches, the fastest one counts: a burst during which the host enqueues more slowly than the
-    # 0.17 ms kernel runs (one was seen at 0.29 ms per launch right after the host-mode legs had released 10 GB of arrays)
-    # measures the host, not the kernel; all bursts are reported
+    # 0.17 ms kernel runs (one was seen at 0.29 ms per launch right after 10 GB of buffers had been released) measures the
+    # host, not the kernel; all bursts are reported
     bursts = []
     for _ in range(3):
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -633,11 +633,6 @@ def main(argv=None):
         # short shard" from "the ranks interfere" when the two are compared over N
         out["throughput"] = {"value": out["pipelined"]["value"], "unit": "voxels/s", "n_gpus": world,
                              "mode": "two passes in flight per rank on its shard; voxels of the whole volume x passes / max over ranks"}
-    if args.workload == "triexp" and not args.no_secondary and rank == 0:
-        # the two sub-millisecond roofline probes run before the host-mode legs: those release ~10 GB of host arrays, and a
-        # launch burst right after that was seen to be host-bound (0.29 ms per enqueue)
-        out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
-        out["roofline_mfma"] = mfma_roofline(device, torch)
     solo = rank == 0 and world == 1
     if solo and not args.no_host_mode:
         out["host_mode"] = leg.host_mode()
@@ -676,6 +671,15 @@ def main(argv=None):
         out["secondary"] = sec
         del leg2
         torch.cuda.empty_cache()
+    if args.workload == "triexp" and not args.no_secondary and rank == 0:
+        # The two sub-millisecond roofline probes.  Whatever runs right after gigabytes of device memory have been released is
+        # slow for a few hundred milliseconds on this box (measured both ways round: the sweep's launch burst at 0.29 ms per
+        # enqueue right after the NNLS leg was freed; the host-mode leg at 68-77 ms instead of 51 when it followed the probes'
+        # buffers): the frees are given a second to settle, and the sweep reports the best of three bursts.
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
+        out["roofline_mfma"] = mfma_roofline(device, torch)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
