@@ -720,7 +720,10 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     // The (n_vox, n_bins) coefficient array is 8.4 GB for the C4 volume: its D2H and first-touch faults hide behind
     // the solves of the following chunks.
     std::lock_guard<std::mutex> plan_lock(plan->mu);
-    const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 1 << 18, 1024, 1 << 22);
+    // every chunk is one launch of the solver plus (block kernel) one hand-over pass of ~8 ms: C4 from numpy arrays takes
+    // 759 / 712 / 682 / 698 ms with chunks of 256 Ki / 512 Ki / 768 Ki / 1 Mi voxels (profiles/nnls_host_chunk.py) -- beyond
+    // 768 Ki the last chunk's download (2 KB per voxel) is what grows
+    const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 3 << 18, 1024, 1 << 22);
     const int n_chunks = (int)((nv + chunk - 1) / chunk);
     const int n_slots = n_chunks < 3 ? n_chunks : 3;
     const size_t cap = nv < chunk ? nv : chunk;
