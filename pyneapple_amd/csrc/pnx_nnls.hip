@@ -871,9 +871,13 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
     P->n_waves = occ * cus;
     P->mglob_stride = kGlobTri;
+    // a block-kernel plan runs this kernel only on the voxels handed over (a quarter of the grid, A^T y on the VALU): a quarter
+    // of the slabs, and no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
+    if (P->blk) P->n_waves = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
     PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * kGlobTri * sizeof(double)));
-    if (!getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64) {  // LDS stage of Bp: n_meas * 2 KiB
-        PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
+    P->mfma_ok = !getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64;  // LDS stage of Bp: n_meas * 2 KiB
+    if (P->mfma_ok) {
+        if (!P->blk) PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
         PNX_HIPN(hipFuncSetAttribute((const void *)nnls_aty_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     PNX_HIPN(hipDeviceSynchronize());
@@ -965,8 +969,8 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
     a.redo_list = list;
     a.redo_count = count;
     PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-    // a quarter of the persistent grid: with an empty list a wave costs one queue pull
-    long long grid = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
+    // the plan's (quartered) persistent grid: with an empty list a wave costs one queue pull
+    long long grid = P->n_waves;
     if (grid > n_vox) grid = n_vox;
     hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
     PNX_HIPN(hipGetLastError());
@@ -974,7 +978,8 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
 }
 
 int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream) {
-    if (!P->aty) return set_error(PNX_ERR_UNSUPPORTED, "the MFMA Gram step is disabled for this plan (n_meas=%d)", P->n_meas);
+    if (!P->mfma_ok) return set_error(PNX_ERR_UNSUPPORTED, "the MFMA Gram step is disabled for this plan (n_meas=%d)", P->n_meas);
+    if (!aty_d && !P->aty) PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));  // first use by a block-kernel plan
     if (n_vox > kAtyChunk) return set_error(PNX_ERR_INVALID, "n_vox=%lld > %lld per call", (long long)n_vox, (long long)kAtyChunk);
     const int kpad = (P->n_meas + 3) & ~3;
     const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);

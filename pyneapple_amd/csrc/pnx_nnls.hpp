@@ -24,6 +24,7 @@ struct NnlsPlanData {
     int n_waves = 0;          // persistent waves the scratch was sized for
     double rc[5] = {0, 0, 0, 0, 0};  // banded Toeplitz regulariser (orders 1-3 of the reference): reg[i][j] = rc[j - i + 2]
     int rhb = 0;              // its half bandwidth, 0 = general regulariser
+    bool mfma_ok = false;     // the MFMA Gram step can run for this plan (n_meas <= 64)
     bool qr = false;          // no (or an all-zero) regulariser and <= 64 measurements: QR-based kernel (pnx_nnls_qr.hip)
     bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
