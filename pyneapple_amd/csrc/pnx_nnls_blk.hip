@@ -43,7 +43,8 @@ namespace pnx {
 constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
 constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
 #ifndef PNX_BLK_WAVES
-#define PNX_BLK_WAVES 12  // 168 registers per wave: 16 waves (128 registers) spill in every phase and run 17 % slower
+#define PNX_BLK_WAVES 12  // 168 registers per wave.  16 waves (128 registers): 62-83 spilled registers and 17 % slower; with the row-wise
+                         // path for rows >= 48 taken out (33 spills, wrong results) still only 3.5 % ahead of 12 waves
 #endif
 constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU
 constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
@@ -349,13 +350,23 @@ struct VoxState {
 };
 
 // blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
+// The block rows of M that live in the global slab (8 I >= kLdsM), K <= I < NI: every load is issued before the first use.
 template <int NI> __device__ __forceinline__ void load_blocks(const MRef &M, int la, int lb, double (&blk)[NI][NI]) {
 #pragma unroll
-    for (int I = NI - 1; I >= 0; --I) {  // the global block rows first: their loads have the longer way
+    for (int I = 0; I < NI; ++I) {
+        if (8 * I < kLdsM) continue;
         const int base = (I + 1) * (32 * I + 8 * la) + lb;
 #pragma unroll
-        for (int K = 0; K <= I; ++K) blk[I][K] = 8 * I < kLdsM ? M.l[base + 8 * K] : M.g[CK(base + 8 * K, kMSlab, 1, I)];
+        for (int K = 0; K <= I; ++K) blk[I][K] = M.g[CK(base + 8 * K, kMSlab, 1, I)];
     }
+}
+// Block row I of M: out of LDS when it is needed (short latency, no register held meanwhile), else the preloaded copy.
+template <int NI> __device__ __forceinline__ void block_row(const MRef &M, int I, int la, int lb, const double (&blk)[NI][NI],
+                                                            double (&row)[NI]) {
+    const int base = (I + 1) * (32 * I + 8 * la) + lb;
+#pragma unroll
+    for (int K = 0; K < NI; ++K)
+        if (K <= I) row[K] = 8 * I < kLdsM ? M.l[base + 8 * K] : blk[I][K];
 }
 
 // Column jmax wants to enter.  l = M g (g = G[P, jmax]), lam^2 = G_jj - |l|^2, Lawson-Hanson independence test; when it
@@ -385,15 +396,16 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     double ll = 0;
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
-        double acc = 0;
+        double acc = 0, row[NI];
+        block_row<NI>(M, I, la, lb, blk, row);
 #pragma unroll
-        for (int K = 0; K <= I; ++K) acc = fma(blk[I][K], gc[K], acc);
+        for (int K = 0; K <= I; ++K) acc = fma(row[K], gc[K], acc);
         double lr = allreduce_b(acc);  // l_{8 I + a}, the same in the lanes (a, *)
         // rows >= p: zero in the LDS part of M (kept so: no mask); in the global part they may hold a previous voxel's values
         if (8 * I >= kLdsM) lr = (8 * I + la < p) ? lr : 0.0;
         ll = fma(lr, lr, ll);
 #pragma unroll
-        for (int K = 0; K <= I; ++K) rK[K] = fma(blk[I][K], lr, rK[K]);
+        for (int K = 0; K <= I; ++K) rK[K] = fma(row[K], lr, rK[K]);
     }
     ll = allreduce_a(ll);
     // rows >= 48: row by row (lanes over the columns), four rows in flight
@@ -513,10 +525,13 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
     lds_order();
     double zK[NI];
 #pragma unroll
-    for (int K = 0; K < NI; ++K) {
-        zK[K] = 0;
+    for (int K = 0; K < NI; ++K) zK[K] = 0;
 #pragma unroll
-        for (int I = K; I < NI; ++I) zK[K] = fma(blk[I][K], qr[I], zK[K]);
+    for (int I = 0; I < NI; ++I) {
+        double row[NI];
+        block_row<NI>(M, I, la, lb, blk, row);
+#pragma unroll
+        for (int K = 0; K <= I; ++K) zK[K] = fma(row[K], qr[I], zK[K]);
     }
     S.z[0] = reduce_scatter_a<NI>(zK, la);
 #pragma unroll
