@@ -207,8 +207,13 @@ class CurvefitLeg:
                 "value": self.n_vox_total * steps / dt, "unit": "voxels/s", "steps": steps, "steps_in_flight": 2,
                 "ms_per_step": dt / steps * 1e3, "results_identical_across_buffers": same}
 
-    def host_mode(self, reps=2):
-        """The same fit through PNX_MEM_HOST: numpy signal in, numpy popt / pcov / status / nfev / cost out (PCIe inclusive)."""
+    def host_mode(self, reps=None):
+        """The same fit through PNX_MEM_HOST: numpy signal in, numpy popt / pcov / status / nfev / cost out (PCIe inclusive).
+        Two timed calls for the big volumes, six for a call of a few ms (C1 / C2: one slow call -- the box sometimes takes
+        12 ms instead of 4.5 for C2 right after another leg's buffers were released -- would otherwise be half the figure);
+        the figure is the median, every call is in ms_reps."""
+        if reps is None:
+            reps = 2 if self.n_vox >= (1 << 21) else 6
         y = self.y.cpu().numpy()
         kw = dict(max_nfev=250, ftol=1e-8, jac=self.jac, want_pcov=self.want_pcov, device=self.device.index)
         r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)  # warm-up (slots, first-touch)
@@ -218,7 +223,7 @@ class CurvefitLeg:
             t = time.perf_counter()
             r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)
             ts.append(time.perf_counter() - t)
-        dt = float(np.mean(ts))
+        dt = float(np.median(ts))
         d2h = sum(a.nbytes for a in r.values() if a is not None)
         same = bool((self.torch.from_numpy(r["popt"]).to(self.popt.device) == self.popt).all().item())
         return {"workload": "same volume, host (numpy) arrays in and out through PNX_MEM_HOST", "value": self.n_vox / dt,

@@ -117,6 +117,13 @@ int pnx_last_error(char *buf, int n);
 int pnx_model_n_params(int model);
 
 /*
+ * PNX_MEM_HOST curve-fit calls with shared p0 / bounds keep one device staging slab (the volume's signal and results,
+ * up to PNX_STREAM_CACHE_MB, default 8192), a pinned control block and their streams per device for the next call.
+ * This frees them; PNX_ERR_INVALID while such a call is running on the device.
+ */
+int pnx_release_staging(int device);
+
+/*
  * Batched bounded non-linear least squares, fp64, results matching SciPy 1.15 curve_fit(method="trf").
  * Replaces: CurveFitSolver._fit_data (curvefit.py:171-244) for all voxels at once.
  *

@@ -89,6 +89,11 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
     return dict(popt=popt, pcov=pcov, status=status, nfev=nfev, cost=cost)
 
 
+def release_staging(device=0):
+    """Free the device staging slab / pinned block / streams a streamed host-array curve fit keeps for the next call."""
+    check(load().pnx_release_staging(int(device)))
+
+
 def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, device, stream=None):
     """Enqueue a batched fit on HBM-resident torch tensors (asynchronous; caller synchronises).  float32 tensors
     select the fp32-storage entry point."""

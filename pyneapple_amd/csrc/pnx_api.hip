@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -139,7 +140,7 @@ static int run_pipeline(int n_chunks, int n_slots, int k_streams, int touchers, 
         stop.store(true);
         sh.cv.notify_all();
     };
-    hipStream_t s_in = nullptr, s_out = nullptr, s_k[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr, s_k[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev(n_chunks, nullptr);
     auto cleanup = [&]() {
         if (s_in) (void)hipStreamDestroy(s_in);
@@ -150,9 +151,14 @@ static int run_pipeline(int n_chunks, int n_slots, int k_streams, int touchers, 
             if (e) (void)hipEventDestroy(e);
     };
     {
-        hipError_t e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking);
-        for (int i = 0; i < k_streams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&s_k[i], hipStreamNonBlocking);
+        // kernel streams at the lowest priority: hardware queues are pooled per priority, so a copy never sits in a queue
+        // behind a chunk's kernel (see curvefit_streamed)
+        int prio_least = 0, prio_greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        const int prio_other = prio_least > 0 ? 0 : prio_greatest;
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s_in, hipStreamNonBlocking, prio_other);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s_out, hipStreamNonBlocking, prio_other);
+        for (int i = 0; i < k_streams && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&s_k[i], hipStreamNonBlocking, prio_least);
         for (int k = 0; k < n_chunks && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
         if (e != hipSuccess) {
             cleanup();
@@ -301,12 +307,28 @@ static launch_fn g_launch[7] = {pnx_launch_curvefit_m0, pnx_launch_curvefit_m1, 
                                 pnx_launch_curvefit_m3, pnx_launch_curvefit_m4, pnx_launch_curvefit_m5,
                                 pnx_launch_curvefit_m6};
 
+// what a streamed launch adds to the kernel arguments (CurvefitArgs::ctl ...); phase 2 = covariance epilogue only
+struct StreamLaunch {
+    StreamCtl *ctl = nullptr;
+    unsigned int *host_flags = nullptr;
+    int granule_shift = 0;
+    unsigned int spins = 0;
+    int phase = 0;
+};
+
 static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y_d,
                            const double *p0, const double *lo, const double *hi, const double *fixed, double *popt_d,
                            double *pcov_d, int8_t *status_d, int32_t *nfev_d, double *cost_d, DeviceInfo *dev,
-                           hipStream_t stream) {
+                           hipStream_t stream, const StreamLaunch *sl = nullptr) {
     CurvefitArgs a;
     memset(&a, 0, sizeof(a));
+    if (sl) {
+        a.ctl = sl->ctl;
+        a.host_flags = sl->host_flags;
+        a.granule_shift = sl->granule_shift;
+        a.stream_spins = sl->spins;
+        a.phase = sl->phase;
+    }
     a.y = y_d;
     a.popt = popt_d;
     a.pcov = pcov_d;
@@ -345,8 +367,10 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
         else
             for (int k = 0; k < o->n_fixed; ++k) a.fixeds[k] = fixed[k];
     }
-    a.queue = next_queue(dev);
-    PNX_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), stream));
+    if (a.phase != 2) {
+        a.queue = next_queue(dev);
+        PNX_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), stream));
+    }
     return g_launch[o->model](o->n_free, o->jac_mode, &a, dev->cus, (void *)stream);
 }
 
@@ -439,6 +463,316 @@ struct AsyncBuf {
     }
 };
 
+// ---- host-pointer calls, streamed --------------------------------------------------------------------------------
+// The chunk ring above launches one persistent kernel per chunk, and every one of them ends in a drain tail (lanes whose
+// queue ran dry idle until the slowest voxel of their wave has converged): seven tails cost C3 about 10 ms of its 50.
+// With shared p0 / bounds and no fixed parameters the whole call is ONE kernel instead (CurvefitArgs::ctl):
+//   IN    uploads the signal piece by piece and moves the kernel's watermark behind each piece (an 8-byte copy on the
+//         same stream, so the data is there before the watermark says so);
+//   the kernel's lanes pull voxels in ascending order and wait at the watermark; each wave counts itself out of a granule
+//         of voxels once it holds nothing below the granule's end, after a system-scope release of its stores; the wave
+//         that completes a granule's count raises a flag in pinned host memory;
+//   OUT   polls the flags and, granule by granule, runs the covariance epilogue and downloads the results while the
+//         kernel is still fitting.
+// The kernel never waits for another kernel, only for the watermark, and that wait is bounded (stream_spins polls, or the
+// abort word) so the grid drains whatever happens on the host; a call whose kernel gave up is run again through the ring.
+static constexpr int kStreamRetry = -1000;  // internal: "use the chunk ring"
+
+// Device slab, pinned control block and streams of a streamed call.  One set per device is kept between calls (a 2 GB
+// hipMalloc / hipFree pair and five stream creations cost 2-3 ms of a 42 ms call); a second call arriving while it is in use
+// works on a private set.  pnx_release_staging() frees the kept set.
+struct StreamRes {
+    void *slab = nullptr;
+    size_t slab_bytes = 0;
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+    std::vector<hipStream_t> s;  // [0] uploads, [1] the persistent kernel (lowest priority), [2..] downloads
+    int ensure_slab(size_t bytes) {
+        if (slab_bytes >= bytes) return PNX_OK;
+        if (slab) (void)hipFree(slab);
+        slab = nullptr;
+        slab_bytes = 0;
+        hipError_t e = hipMalloc(&slab, bytes);
+        if (e != hipSuccess) return set_error(PNX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        slab_bytes = bytes;
+        return PNX_OK;
+    }
+    int ensure_pin(size_t bytes) {
+        if (pin_bytes >= bytes) return PNX_OK;
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr;
+        pin_bytes = 0;
+        bytes = (bytes + 65535) & ~(size_t)65535;
+        PNX_HIP(hipHostMalloc(&pin, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+        pin_bytes = bytes;
+        return PNX_OK;
+    }
+    int ensure_streams(int n) {
+        // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a packet queued
+        // behind the persistent kernel in ITS hardware queue would wait for the kernel's end -- which, for the upload, never
+        // comes (measured: with torch's streams in the process the uploads sat behind the kernel until its poll limit).
+        // Queues are pooled per priority, so the kernel's stream gets the lowest priority and a queue of its own; copies and
+        // epilogues stay at the default priority (and win the dispatch arbitration against the fit, which is what one wants).
+        int prio_least = 0, prio_greatest = 0;
+        PNX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        const int prio_other = prio_least > 0 ? 0 : prio_greatest;  // numerically lower = higher priority
+        while ((int)s.size() < n) {
+            hipStream_t q = nullptr;
+            PNX_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, s.size() == 1 ? prio_least : prio_other));
+            s.push_back(q);
+        }
+        return PNX_OK;
+    }
+    void release() {
+        if (slab) (void)hipFree(slab);
+        if (pin) (void)hipHostFree(pin);
+        for (auto q : s)
+            if (q) (void)hipStreamDestroy(q);
+        slab = pin = nullptr;
+        slab_bytes = pin_bytes = 0;
+        s.clear();
+    }
+};
+static StreamRes g_sres[64];
+static bool g_sres_busy[64] = {false};
+
+struct StreamLease {
+    StreamRes *r = nullptr;
+    int device = 0;
+    bool kept = false;
+    explicit StreamLease(int dev) : device(dev) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_sres_busy[dev]) {
+            g_sres_busy[dev] = true;
+            r = &g_sres[dev];
+            kept = true;
+        } else {
+            r = new StreamRes();
+        }
+    }
+    ~StreamLease() {
+        if (kept) {
+            const size_t cap = (size_t)env_int("PNX_STREAM_CACHE_MB", 8192, 0, 1 << 20) << 20;
+            if (r->slab_bytes > cap) {
+                (void)hipFree(r->slab);
+                r->slab = nullptr;
+                r->slab_bytes = 0;
+            }
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_sres_busy[device] = false;
+        } else {
+            r->release();
+            delete r;
+        }
+    }
+};
+
+template <typename T>
+static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double *bd, const T *y, const double *p0d,
+                             const double *lod, const double *hid, T *popt, T *pcov, int8_t *status, int32_t *nfev,
+                             T *cost, int gshift, DeviceInfo *dev, int device, hipStream_t user_stream) {
+    constexpr bool F32 = sizeof(T) == 4;
+    const int n = o->n_free, n_b = o->n_b;
+    const size_t G = (size_t)1 << gshift;
+    const int n_gran = (int)((nv + G - 1) >> gshift);
+    const size_t in_piece = (size_t)env_int("PNX_STREAM_IN_CHUNK", 1 << 17, 1024, 1 << 26);  // voxels per upload / watermark step
+    const int n_in = (int)((nv + in_piece - 1) / in_piece);
+    const bool need_stat = status || pcov, need_cost = cost || pcov;
+    const bool trace = getenv("PNX_HOST_TRACE") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    if (user_stream) PNX_HIP(hipStreamSynchronize(user_stream));
+
+    // device: the whole volume's fp64 working set (+ the T-typed transfer buffers of the float32 entry point) + control block
+    StreamLease lease(device);
+    StreamRes &res = *lease.r;
+    double *dy = nullptr, *dpopt = nullptr, *dpcov = nullptr, *dcost = nullptr;
+    T *ty = nullptr, *tpopt = nullptr, *tpcov = nullptr, *tcost = nullptr;
+    int8_t *dstat = nullptr;
+    int32_t *dnfev = nullptr;
+    StreamCtl *ctl = nullptr;
+    const size_t ctl_bytes = sizeof(StreamCtl) + sizeof(unsigned int) * (size_t)n_gran;
+    int rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        Carver c;
+        c.base = (char *)res.slab;
+        auto both = [&](double *&d64, T *&t, size_t count) {
+            d64 = (double *)c.take(count * sizeof(double));
+            t = F32 ? (T *)c.take(count * sizeof(T)) : (T *)d64;
+        };
+        both(dy, ty, nv * n_b);
+        both(dpopt, tpopt, nv * n);
+        if (pcov) both(dpcov, tpcov, nv * n * n);
+        if (need_stat) dstat = (int8_t *)c.take(nv);
+        if (nfev) dnfev = (int32_t *)c.take(nv * sizeof(int32_t));
+        if (need_cost) both(dcost, tcost, nv);
+        ctl = (StreamCtl *)c.take(ctl_bytes);
+        if (pass == 0 && (rc = res.ensure_slab(c.off))) return rc;
+    }
+    // pinned host: granule flags (written by the kernel), watermark values (source of the 8-byte copies), the abort word
+    const size_t pin_bytes = sizeof(unsigned long long) * (size_t)(n_in + 1) + sizeof(unsigned int) * (size_t)n_gran;
+    if ((rc = res.ensure_pin(pin_bytes))) return rc;
+    memset(res.pin, 0, pin_bytes);
+    unsigned long long *wm = (unsigned long long *)res.pin;  // [n_in], then one word holding the abort value
+    unsigned int *abort_src = (unsigned int *)(wm + n_in);
+    *abort_src = 1u;
+    volatile unsigned int *flags = (volatile unsigned int *)(wm + n_in + 1);
+    unsigned int *flags_dev = nullptr;
+    PNX_HIP(hipHostGetDevicePointer((void **)&flags_dev, (void *)flags, 0));
+
+    // the downloads are pageable copies (the runtime pins the destination pages piece by piece): two threads, each with its
+    // own stream and every other granule, keep up with the kernel where one falls 13 ms behind (C3, profiles/stream_sweep.py)
+    const int n_out = env_int("PNX_STREAM_OUT_THREADS", 2, 1, 4);
+    if ((rc = res.ensure_streams(2 + n_out))) return rc;
+    hipStream_t s_in = res.s[0], s_main = res.s[1];
+    PNX_HIP(hipMemsetAsync(ctl, 0, ctl_bytes, s_main));
+    PNX_HIP(hipStreamSynchronize(s_main));  // the control block is clean before anybody moves the watermark
+
+    StreamLaunch sl;
+    sl.ctl = ctl;
+    sl.host_flags = flags_dev;
+    sl.granule_shift = gshift;
+    sl.spins = (unsigned int)env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 30);  // ~6 us per poll
+    sl.phase = 1;
+    rc = curvefit_device(o, (int64_t)nv, bd, dy, p0d, lod, hid, nullptr, dpopt, dpcov, dstat, dnfev, dcost, dev, s_main, &sl);
+    if (rc) return rc;
+    const double t_launched = now();
+
+    std::atomic<bool> failed(false), kernel_done(false);
+    std::mutex err_mu;
+    int err_code = PNX_OK;
+    std::string err_msg;
+    auto fail = [&](int code) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (!failed.load()) {
+            err_code = code;
+            err_msg = g_err;
+            failed.store(true);
+        }
+    };
+    std::vector<double> t_in(n_in), t_flag(n_gran), t_out(n_gran);
+    std::vector<std::atomic<int>> claim(n_gran), touched(n_gran);
+    for (int g = 0; g < n_gran; ++g) {
+        claim[g].store(0);
+        touched[g].store(0);
+    }
+    auto touch = [&](int g) {
+        const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
+        for (int j = 0; j < n; ++j) touch_pages(popt + j * nv + v0, c * sizeof(T));
+        if (pcov) touch_pages(pcov + v0 * n * n, c * n * n * sizeof(T));
+        if (status) touch_pages(status + v0, c);
+        if (nfev) touch_pages(nfev + v0, c * sizeof(int32_t));
+        if (cost) touch_pages(cost + v0, c * sizeof(T));
+    };
+    std::vector<std::thread> th;
+    th.emplace_back([&]() {  // IN
+        auto body = [&]() -> int {
+            PNX_HIP(hipSetDevice(device));
+            if (const int ms = env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000))  // tests: a stalled upload
+                std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+            for (int i = 0; i < n_in && !failed.load(); ++i) {
+                const size_t v0 = (size_t)i * in_piece, c = std::min(in_piece, nv - v0);
+                PNX_HIP(hipMemcpyAsync(ty + v0 * n_b, y + v0 * n_b, c * n_b * sizeof(T), hipMemcpyHostToDevice, s_in));
+                if constexpr (F32) {
+                    int r = cvt(ty + v0 * n_b, dy + v0 * n_b, c * n_b, s_in);
+                    if (r) return r;
+                }
+                wm[i] = v0 + c;
+                PNX_HIP(hipMemcpyAsync(&ctl->ready, &wm[i], sizeof(unsigned long long), hipMemcpyHostToDevice, s_in));
+                t_in[i] = now();
+            }
+            PNX_HIP(hipStreamSynchronize(s_in));
+            return PNX_OK;
+        };
+        const int r = body();
+        if (r) {
+            fail(r);
+            // tell the kernel to stop waiting (best effort: its own poll limit ends the wait otherwise)
+            (void)hipMemcpyAsync(&ctl->abort, abort_src, sizeof(unsigned int), hipMemcpyHostToDevice, s_in);
+            (void)hipStreamSynchronize(s_in);
+        }
+    });
+    for (int ot = 0; ot < n_out; ++ot) th.emplace_back([&, ot]() {  // OUT
+        hipStream_t s_out = res.s[2 + ot];
+        auto body = [&]() -> int {
+            PNX_HIP(hipSetDevice(device));
+            StreamLaunch s2;
+            s2.phase = 2;
+            for (int g = ot; g < n_gran; g += n_out) {
+                int expect = 0;
+                if (claim[g].compare_exchange_strong(expect, 1)) {  // no helper got here yet: touch it ourselves
+                    touch(g);
+                    touched[g].store(1);
+                } else {
+                    while (!touched[g].load()) std::this_thread::yield();
+                }
+                for (;;) {
+                    if (__atomic_load_n(&flags[g], __ATOMIC_ACQUIRE)) break;
+                    if (failed.load()) return PNX_OK;
+                    if (kernel_done.load()) {  // the kernel raises every flag before it ends
+                        if (__atomic_load_n(&flags[g], __ATOMIC_ACQUIRE)) break;
+                        return set_error(PNX_ERR_HIP, "streamed curve fit: kernel ended without completing granule %d", g);
+                    }
+                    std::this_thread::yield();
+                }
+                t_flag[g] = now();
+                const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
+                if (pcov) {
+                    int r = curvefit_device(o, (int64_t)c, bd, nullptr, p0d, lod, hid, nullptr, nullptr, dpcov + v0 * n * n,
+                                            dstat + v0, nullptr, dcost + v0, dev, s_out, &s2);
+                    if (r) return r;
+                }
+                if constexpr (F32) {
+                    int r = PNX_OK;
+                    for (int j = 0; j < n && !r; ++j) r = cvt(dpopt + j * nv + v0, tpopt + j * nv + v0, c, s_out);
+                    if (!r && pcov) r = cvt(dpcov + v0 * n * n, tpcov + v0 * n * n, c * n * n, s_out);
+                    if (!r && cost) r = cvt(dcost + v0, tcost + v0, c, s_out);
+                    if (r) return r;
+                }
+                for (int j = 0; j < n; ++j)
+                    PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, tpopt + j * nv + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
+                if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, tpcov + v0 * n * n, c * n * n * sizeof(T), hipMemcpyDeviceToHost, s_out));
+                if (status) PNX_HIP(hipMemcpyAsync(status + v0, dstat + v0, c, hipMemcpyDeviceToHost, s_out));
+                if (nfev) PNX_HIP(hipMemcpyAsync(nfev + v0, dnfev + v0, c * sizeof(int32_t), hipMemcpyDeviceToHost, s_out));
+                if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, tcost + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
+                PNX_HIP(hipStreamSynchronize(s_out));
+                t_out[g] = now();
+            }
+            return PNX_OK;
+        };
+        const int r = body();
+        if (r) fail(r);
+    });
+    const int touchers = env_int("PNX_HOST_TOUCHERS", 2, 0, 8);
+    for (int t = 0; t < touchers; ++t)
+        th.emplace_back([&]() {
+            for (int g = 0; g < n_gran && !failed.load(); ++g) {
+                int expect = 0;
+                if (claim[g].compare_exchange_strong(expect, 1)) {
+                    touch(g);
+                    touched[g].store(1);
+                }
+            }
+        });
+    hipError_t ke = hipStreamSynchronize(s_main);
+    const double t_kernel = now();
+    kernel_done.store(true);
+    for (auto &t : th) t.join();
+    if (ke != hipSuccess) return set_error(PNX_ERR_HIP, "streamed curve fit kernel: %s", hipGetErrorString(ke));
+    StreamCtl head;
+    PNX_HIP(hipMemcpy(&head, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost));
+    if (trace) {
+        fprintf(stderr, "[pnx stream] %d granules of %zu voxels, %d upload pieces; launched %.2f kernel_done %.2f all_done %.2f ms%s\n",
+                n_gran, G, n_in, t_launched, t_kernel, now(), head.timed_out ? " TIMED OUT" : "");
+        for (int i = 0; i < n_in; i += std::max(1, n_in / 8)) fprintf(stderr, "[pnx stream] upload piece %d enqueued by %.2f ms\n", i, t_in[i]);
+        for (int g = 0; g < n_gran; g += std::max(1, n_gran / 8))
+            fprintf(stderr, "[pnx stream] granule %d complete at %.2f, downloaded by %.2f ms\n", g, t_flag[g], t_out[g]);
+    }
+    if (failed.load()) return set_error(err_code, "%s", err_msg.c_str());
+    if (head.timed_out) return kStreamRetry;
+    return PNX_OK;
+}
+
 // T = double: the fp64 entry point.  T = float: fp32 STORAGE (signal, p0 / bounds / fixed maps in, popt / pcov / cost
 // out) with the same fp64 arithmetic -- what the reference does with a float32 image (curve_fit casts ydata to float64).
 template <typename T>
@@ -503,6 +837,22 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
             if (pcov && (rc = cvt((const double *)c64.p, pcov, nv * n * n, st))) return rc;
             if (cost && (rc = cvt((const double *)k64.p, cost, nv, st))) return rc;
             return PNX_OK;  // AsyncBuf destructors enqueue the frees behind the conversions
+        }
+    }
+
+    // ---- host staging, streamed: one persistent kernel for the whole volume (curvefit_streamed above)
+    {
+        // granule = unit of the download (and of the completion flags): 256 Ki voxels for volumes of 2 Mi voxels and more,
+        // 128 Ki below (C3: 2^17 41.4-44 ms, 2^18 40.6-43.9 ms, 2^16 and 2^19 42-45 ms; profiles/stream_sweep.py)
+        const int gshift = env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
+        const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2) * (F32 ? 12 : 8);
+        const size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
+        if (!pv && !o->n_fixed && env_int("PNX_HOST_STREAM", 1, 0, 1) && nv > ((size_t)1 << gshift) && nv < ((size_t)1 << 31) &&
+            nv * per_vox <= max_bytes) {
+            rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, popt, pcov, status, nfev, cost, gshift, dev, device,
+                                      (hipStream_t)stream);
+            if (rc != kStreamRetry) return rc;
+            if (getenv("PNX_HOST_TRACE")) fprintf(stderr, "[pnx stream] watermark wait timed out; running the call through the chunk ring\n");
         }
     }
 
@@ -625,10 +975,24 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.tcost, c * sizeof(T), hipMemcpyDeviceToHost, st));
         return PNX_OK;
     };
-    return run_pipeline(n_chunks, n_slots, 2, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), device, (hipStream_t)stream, ops);
+    return run_pipeline(n_chunks, n_slots, env_int("PNX_HOST_KSTREAMS", 2, 1, 4), env_int("PNX_HOST_TOUCHERS", 2, 0, 8), device, (hipStream_t)stream, ops);
 }
 
 extern "C" {
+int pnx_release_staging(int device) {
+    if (device < 0 || device >= 64) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_sres_busy[device]) return set_error(PNX_ERR_INVALID, "device %d: a streamed call is using the staging set", device);
+    int cur = 0;
+    if (g_sres[device].slab || g_sres[device].pin || !g_sres[device].s.empty()) {
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        g_sres[device].release();
+        (void)hipSetDevice(cur);
+    }
+    return PNX_OK;
+}
+
 int pnx_curvefit_batch_f64(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y,
                            const double *p0, const double *lo, const double *hi, const double *fixed, double *popt,
                            double *pcov, int8_t *status, int32_t *nfev, double *cost, int mem, int device,

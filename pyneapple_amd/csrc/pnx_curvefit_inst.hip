@@ -9,12 +9,25 @@
 
 namespace pnx {
 
-template <int MODEL, int N, bool FD, bool PV, bool T1>
+template <int N> static int launch_pcov(const CurvefitArgs &args, const ColPerm &cp, hipStream_t stream) {
+    const int pb = 256;
+    hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
+                       (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PNX_ERR_HIP, "pcov launch: %s", hipGetErrorString(e));
+    return PNX_OK;
+}
+
+template <int MODEL, int N, bool FD, bool PV, bool T1, bool STREAM = false>
 static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stream) {
-    auto kern = curvefit_kernel<MODEL, N, FD, PV, T1>;
+    ColPerm cp;
+    constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
+    for (int k = 0; k < kMaxP; ++k) cp.p[k] = (N == NP && k < Model<MODEL>::NALL) ? colperm<MODEL>(k) : k;
+    if (args.phase == 2) return args.pcov ? launch_pcov<N>(args, cp, stream) : PNX_OK;
+    auto kern = curvefit_kernel<MODEL, N, FD, PV, T1, STREAM>;
     // LDS per block: b-value table + per wave: [n_b][64] signal tile, parked R factor and singular vectors.
     // Up to 4 waves per block; fewer when that would not fit 160 KiB.
-    int waves = 4;
+    int waves = PNX_CF_BLOCK_WAVES;
     auto bytes = [&](int w) { return sizeof(double) * (kMaxB + (size_t)w * Park<N>::per_wave(args.n_b)); };
     while (waves > 1 && bytes(waves) > 160 * 1024) --waves;
     if (bytes(waves) > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", args.n_b);
@@ -39,20 +52,19 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, args);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "curvefit launch: %s", hipGetErrorString(e));
-    if (args.pcov) {
-        const int pb = 256;
-        ColPerm cp;
-        constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
-        for (int k = 0; k < kMaxP; ++k) cp.p[k] = (N == NP && k < Model<MODEL>::NALL) ? colperm<MODEL>(k) : k;
-        hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
-                           (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp);
-        e = hipGetLastError();
-        if (e != hipSuccess) return set_error(PNX_ERR_HIP, "pcov launch: %s", hipGetErrorString(e));
-    }
+    if (args.pcov && args.phase == 0) return launch_pcov<N>(args, cp, stream);
     return PNX_OK;
 }
 
 template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
+    if (args.ctl && args.phase != 2) {
+        // streamed launches exist for shared p0 / bounds with every parameter free (what the host path asks for)
+        constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
+        if constexpr (N == NP) {
+            if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
+        }
+        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch needs shared p0 / bounds and no fixed parameters");
+    }
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }
 

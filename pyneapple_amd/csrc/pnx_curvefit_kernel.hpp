@@ -42,6 +42,15 @@ constexpr double kEps = 2.220446049250313e-16;
 constexpr double kSqrtEps = 1.4901161193847656e-08;
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Control block of a streamed launch.  `ready` is written by 8-byte H2D copies enqueued behind each granule's upload (stream
+// order = data before watermark); `done[g]` counts the waves that will never touch granule g again.
+struct StreamCtl {
+    unsigned long long ready;  // voxels [0, ready) are resident
+    unsigned int abort;        // host -> kernel: stop pulling voxels
+    unsigned int timed_out;    // kernel -> host: a lane gave up waiting for the watermark
+    unsigned int done[1];      // [n_granules]
+};
+
 struct CurvefitArgs {
     const double *y;      // (n_vox, n_b)
     const double *p0;     // (N, n_vox) when per_voxel
@@ -54,6 +63,13 @@ struct CurvefitArgs {
     int32_t *nfev;
     double *cost;
     unsigned long long *queue;  // work-queue head, zeroed before launch
+    // Streamed launch (host-pointer calls, pnx_api.hip `curvefit_streamed`): ONE persistent kernel runs while the volume is
+    // still being uploaded and its results are already being downloaded.  ctl != null selects the STREAM instantiation.
+    StreamCtl *ctl;             // device memory: upload watermark, abort word, per-granule wave counts
+    unsigned int *host_flags;   // pinned host memory: host_flags[g] = 1 once every wave has left granule g behind
+    int granule_shift;          // granule = 1 << granule_shift voxels
+    unsigned int stream_spins;  // watermark polls before a lane gives up (ctl->timed_out = 1)
+    int phase;                  // 0: fit + covariance epilogue, 1: fit only, 2: covariance epilogue only
     long long n_vox;
     int n_b;
     int per_voxel;
@@ -640,8 +656,11 @@ template <int N> struct Park {
 #ifndef PNX_CF_WAVES_PER_SIMD
 #define PNX_CF_WAVES_PER_SIMD 1  // 2 was measured at 47-60 M voxels/s (spills, and the LDS park of 8 waves does not fit for n_b = 32)
 #endif
-template <int MODEL, int N, bool FD, bool PV, bool T1>
-__global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(const CurvefitArgs A) {
+#ifndef PNX_CF_BLOCK_WAVES
+#define PNX_CF_BLOCK_WAVES 4
+#endif
+template <int MODEL, int N, bool FD, bool PV, bool T1, bool STREAM = false>
+__global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(const CurvefitArgs A) {
     using M = Model<MODEL>;
     using PK = Park<N>;
     constexpr int NALL = M::NALL;            // parameters of the diffusion model
@@ -669,6 +688,27 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
     // ---- per-lane persistent state
     int state = ST_IDLE;
     long long vox = -1;
+    unsigned long long ready_seen = 0;  // STREAM: last upload watermark this lane saw
+    int pub = 0;                        // STREAM: granules [0, pub) published as left behind by this wave (wave-uniform)
+    // STREAM: the queue hands out ascending indices, so once no lane of the wave holds a voxel of granule <= g the wave
+    // never writes to granule g again.  It then makes its stores visible (system-scope release) and counts itself out of
+    // g; the wave that completes the count raises the host's flag, and the host starts that granule's download while the
+    // kernel keeps running.
+    auto publish = [&](bool all) {
+        const int n_gran = (int)((A.n_vox + (1ll << A.granule_shift) - 1) >> A.granule_shift);
+        int upto = pub;
+        while (upto < n_gran && (all || !__ballot(state != ST_IDLE && (vox >> A.granule_shift) <= upto))) ++upto;
+        if (upto == pub) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const unsigned int n_waves = gridDim.x * (blockDim.x / kWave);
+        if ((threadIdx.x & (kWave - 1)) == __ffsll((unsigned long long)__ballot(1)) - 1) {
+            for (int g = pub; g < upto; ++g) {
+                const unsigned int old = __hip_atomic_fetch_add(&A.ctl->done[g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (old + 1 == n_waves) __hip_atomic_store(&A.host_flags[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        pub = upto;
+    };
     double x[N], lb[N], ub[N];
     double pfull[NP];
     double g[N];
@@ -700,6 +740,27 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
     while (state == ST_IDLE) {
         const unsigned long long idx = atomicAdd(A.queue, 1ULL);
         if (idx >= (unsigned long long)A.n_vox) break;  // queue empty: this lane is done for good
+        if constexpr (STREAM) {
+            // the voxel's signal may still be on its way: wait for the upload watermark (acquire: the rows behind it are
+            // visible).  Bounded: on abort or after stream_spins polls the lane leaves, so the grid always drains.
+            if (idx >= ready_seen) {
+                bool got = false;
+                for (unsigned int spins = 0; spins < A.stream_spins; ++spins) {
+                    ready_seen = __hip_atomic_load(&A.ctl->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (idx < ready_seen) {
+                        got = true;
+                        break;
+                    }
+                    if (__hip_atomic_load(&A.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+                    __builtin_amdgcn_s_sleep(127);
+                }
+                if (!got) {
+                    if (!__hip_atomic_load(&A.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                        __hip_atomic_store(&A.ctl->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;  // leaves with state IDLE
+                }
+            }
+        }
         vox = (long long)idx;
         const double *yv = A.y + (size_t)vox * n_b;
         if (dma_ok) {
@@ -753,6 +814,12 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
     }
     };
     refill();
+    if constexpr (STREAM) {
+        // `pub` is only uniform among the lanes that are still in the loop below (a lane that left keeps the value it left
+        // with), so nothing is published behind the loop: the last lane of the wave to run dry publishes the rest from inside
+        // it, and a wave that never got a voxel does so here.
+        if (!__ballot(state != ST_IDLE)) publish(true);
+    }
     for (;;) {
         CFSTAMP(7);
         if (state == ST_IDLE) break;
@@ -1029,7 +1096,13 @@ __global__ void __launch_bounds__(256, PNX_CF_WAVES_PER_SIMD) curvefit_kernel(co
             state = ST_IDLE;
         }
         CFACT(0, state == ST_IDLE);
-        if (state == ST_IDLE) refill();  // claim the next voxel now: its signal streams in behind phases B / C
+        if constexpr (STREAM) {
+            const bool any_idle = __ballot(state == ST_IDLE) != 0;
+            if (state == ST_IDLE) refill();
+            if (any_idle) publish(false);
+        } else {
+            if (state == ST_IDLE) refill();  // claim the next voxel now: its signal streams in behind phases B / C
+        }
 
         CFSTAMP(3);
         CFACT(4, state == ST_RUN && accepted);

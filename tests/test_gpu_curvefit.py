@@ -347,6 +347,72 @@ def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
     assert (one["status"] > 0).mean() > 0.99
 
 
+@pytest.mark.parametrize("model,n_b,dtype,pcov", [("tri_reduced", 32, np.float64, True), ("bi_reduced", 23, np.float64, False),
+                                                  ("tri_reduced", 32, np.float32, True), ("mono", 16, np.float32, False)])
+def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, model, n_b, dtype, pcov):
+    """Host arrays with shared p0 / bounds run as ONE persistent kernel that waits at an upload watermark and hands finished
+    granules to the download while it is still fitting (pnx_api.hip curvefit_streamed).  Ragged granules, upload pieces that
+    do not line up with granules, odd n_b (no LDS-DMA refill) and the float32 entry point must all return, bit for bit,
+    what the chunk ring returns; the fp64 case also equals the device-resident call."""
+    import torch
+
+    from pyneapple_amd import api, synth
+
+    n_vox = 40000 + 37
+    b, y, _ = synth.make_numpy(model, n_vox, n_b, sigma=0.01, seed=11)
+    y = y.astype(dtype)
+    names, p0, lo, hi = synth.shared_arrays(model)
+    monkeypatch.setenv("PNX_HOST_STREAM", "0")
+    ring = gpu.curvefit(model, b, y, p0, lo, hi, want_pcov=pcov)
+    monkeypatch.setenv("PNX_HOST_STREAM", "1")
+    for shift, piece, touchers in (("10", "1024", "2"), ("12", "3000", "0"), ("11", "65536", "3")):
+        monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", shift)
+        monkeypatch.setenv("PNX_STREAM_IN_CHUNK", piece)
+        monkeypatch.setenv("PNX_HOST_TOUCHERS", touchers)
+        st = gpu.curvefit(model, b, y, p0, lo, hi, want_pcov=pcov)
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            if ring[k] is not None:
+                np.testing.assert_array_equal(st[k], ring[k], err_msg=f"{k} shift={shift}")
+    assert (ring["status"] > 0).mean() > 0.99
+    if dtype is np.float64:
+        dev = torch.device("cuda", 0)
+        n = len(names)
+        popt = torch.empty((n, n_vox), dtype=torch.float64, device=dev)
+        status = torch.empty(n_vox, dtype=torch.int8, device=dev)
+        cost = torch.empty(n_vox, dtype=torch.float64, device=dev)
+        api.curvefit_device(api.make_opts(model, n_b), n_vox, b, torch.from_numpy(y).to(dev), p0, lo, hi, None, popt, None,
+                            status, None, cost, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(popt.cpu().numpy(), ring["popt"])
+        np.testing.assert_array_equal(cost.cpu().numpy(), ring["cost"])
+
+
+def test_streamed_host_path_stalled_upload_falls_back(gpu, monkeypatch, capfd):
+    """The streamed kernel's wait for the upload watermark is bounded: when the upload stalls for longer than the poll
+    limit the lanes leave, the grid drains, and the call is run again through the chunk ring -- same results, no hang."""
+    from pyneapple_amd import synth
+
+    n_vox = 20000
+    b, y, _ = synth.make_numpy("bi_reduced", n_vox, 24, sigma=0.01, seed=3)
+    names, p0, lo, hi = synth.shared_arrays("bi_reduced")
+    monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "12")
+    monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "4096")
+    good = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    monkeypatch.setenv("PNX_STREAM_SPINS", "1000")        # a few ms of polling
+    monkeypatch.setenv("PNX_STREAM_TEST_DELAY_MS", "300")  # the upload starts long after that
+    monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    again = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    assert "timed out" in capfd.readouterr().err
+    for k in ("popt", "pcov", "status", "nfev", "cost"):
+        np.testing.assert_array_equal(again[k], good[k], err_msg=k)
+    # the staging set kept between streamed calls can be dropped, and the next call builds a new one
+    gpu.release_staging(0)
+    monkeypatch.delenv("PNX_STREAM_TEST_DELAY_MS")
+    monkeypatch.delenv("PNX_STREAM_SPINS")
+    third = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    np.testing.assert_array_equal(third["popt"], good["popt"])
+
+
 def test_device_call_is_graph_capturable(gpu):
     """The device-pointer entry point only enqueues (a memset of its queue counter and two kernels): it can be captured
     into a HIP graph and replayed on new signal data, for callers that fit many small batches in a loop."""
