@@ -37,7 +37,7 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = fp64 matrix peak (half the 157.3 TF fp32 rate of MI355X_MICROARCH.md)
 METRIC = "voxels/sec (pixelwise triexp LM & 250-bin NNLS) at 1/2/4/8 MI355X"
-CURVEFIT_C3_KERNEL = "curvefit_kernel<4, 5, true, false, false>"  # rocprofv3's name of the C3 instantiation
+CURVEFIT_C3_KERNEL = "curvefit_kernel<4, 5, true, false, false, false>"  # rocprofv3's name of the C3 instantiation
 NNLS_KERNEL = "nnls_blk_kernel"  # the C4 plan (banded regulariser, 32 measurements): pnx_nnls_blk.hip
 
 
