@@ -10,9 +10,10 @@ bins, basis, reg = synth.nnls_matrices(32)
 _, y, _ = synth.make_numpy("tri_reduced", n, 32, sigma=0.01, scale=1000.0)
 plan = api.NnlsPlan(basis, reg, 0)
 r = plan.solve(y[:65536], 250); del r
-for chunk in (1 << 18, 1 << 19, 3 << 18, 1 << 20):
+for chunk, cap in ((3 << 18, 0), (1 << 17, 16384), (1 << 18, 16384), (1 << 19, 16384), (3 << 18, 16384), (1 << 20, 16384)):
     os.environ["PNX_NNLS_HOST_CHUNK"] = str(chunk)
+    os.environ["PNX_NNLS_DEFER_CAP"] = str(cap)  # 0: one hand-over pass per chunk (the behaviour before the deferral)
     ts = []
     for _ in range(2):
         t = time.perf_counter(); r = plan.solve(y, 250); ts.append(time.perf_counter() - t); del r
-    print(f"chunk {chunk >> 10}k: {[round(t * 1e3) for t in ts]} ms -> {n / min(ts) / 1e6:.2f} M voxels/s", flush=True)
+    print(f"chunk {chunk >> 10}k, hand-over {'deferred to the end of the call' if cap else 'per chunk'}: {[round(t * 1e3) for t in ts]} ms -> {n / min(ts) / 1e6:.2f} M voxels/s", flush=True)

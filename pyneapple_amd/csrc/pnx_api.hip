@@ -607,7 +607,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
         if (nfev) dnfev = (int32_t *)c.take(nv * sizeof(int32_t));
         if (need_cost) both(dcost, tcost, nv);
         ctl = (StreamCtl *)c.take(ctl_bytes);
-        if (pass == 0 && (rc = res.ensure_slab(c.off))) return rc;
+        if (pass == 0 && res.ensure_slab(c.off)) return kStreamRetry;  // no room for the whole volume: the ring needs three chunks
     }
     // pinned host: granule flags (written by the kernel), watermark values (source of the 8-byte copies), the abort word
     const size_t pin_bytes = sizeof(unsigned long long) * (size_t)(n_in + 1) + sizeof(unsigned int) * (size_t)n_gran;
@@ -852,7 +852,10 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
             rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, popt, pcov, status, nfev, cost, gshift, dev, device,
                                       (hipStream_t)stream);
             if (rc != kStreamRetry) return rc;
-            if (getenv("PNX_HOST_TRACE")) fprintf(stderr, "[pnx stream] watermark wait timed out; running the call through the chunk ring\n");
+            static std::atomic<bool> warned(false);
+            if (getenv("PNX_HOST_TRACE") || !warned.exchange(true))
+                fprintf(stderr, "[pnx stream] the streamed launch could not be used (no room for the staging slab, or its wait for the "
+                                "upload timed out); running the call through the chunk ring. PNX_HOST_STREAM=0 skips the attempt.\n");
         }
     }
 
@@ -1088,7 +1091,20 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     // 759 / 712 / 682 / 698 ms with chunks of 256 Ki / 512 Ki / 768 Ki / 1 Mi voxels (profiles/nnls_host_chunk.py) -- beyond
     // 768 Ki the last chunk's download (2 KB per voxel) is what grows
     const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 3 << 18, 1024, 1 << 22);
-    const int n_chunks = (int)((nv + chunk - 1) / chunk);
+    // chunk boundaries.  Block-kernel plans with three or more chunks (their hand-over pass is deferred, see below, so a
+    // chunk more costs ~1.5 ms, not 8): the first and the last piece are a quarter chunk -- the first launch starts after a
+    // quarter of an upload, and the download left exposed at the end is 0.4 GB instead of 1.6 (2 KB per voxel).
+    std::vector<size_t> bounds;
+    {
+        const size_t ramp = (P.blk && env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk) ? chunk / 4 : 0;
+        size_t v = 0;
+        bounds.push_back(0);
+        if (ramp) bounds.push_back(v = ramp);
+        const size_t body_end = nv - ramp;
+        while (v < body_end) bounds.push_back(v = (body_end - v) < chunk ? body_end : v + chunk);
+        if (ramp) bounds.push_back(nv);
+    }
+    const int n_chunks = (int)bounds.size() - 1;
     const int n_slots = n_chunks < 3 ? n_chunks : 3;
     const size_t cap = nv < chunk ? nv : chunk;
     struct Slot {
@@ -1116,49 +1132,121 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
             if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
         }
     }
-    auto span = [&](int k, size_t &off, size_t &c) {
-        off = (size_t)k * chunk;
-        c = (nv - off) < chunk ? (nv - off) : chunk;
-    };
-    PipeOps ops;
-    ops.h2d = [&](int k, int slot, hipStream_t s) -> int {
-        size_t off, c;
-        span(k, off, c);
-        PNX_HIP(hipMemcpyAsync(slots[slot].ty, y + off * P.n_meas, c * P.n_meas * sizeof(T), hipMemcpyHostToDevice, s));
+    // Block-kernel plans hand a few voxels per chunk to the general kernel, and that pass costs ~8 ms per chunk whatever their
+    // number (they are the longest solves there are): with several chunks the hand-over is deferred -- the chunks only
+    // collect the voxels' indices and signal rows, ONE pass at the end of the call solves them, and their rows are patched
+    // into the caller's arrays (C4 from numpy arrays: seven passes -> one).
+    constexpr int kDeferOverflow = -1001;
+    const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
+    const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
+    DevBuf dslab;
+    NnlsDefer dctx{};
+    if (can_defer) {
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)dslab.p;
+            dctx.counters = (int32_t *)c.take(2 * sizeof(int32_t));
+            dctx.bail = (int32_t *)c.take(nv * sizeof(int32_t));
+            dctx.y_side = (double *)c.take((size_t)defer_cap * P.n_meas * sizeof(double));
+            if (pass == 0 && (rc = dslab.alloc(c.off))) return rc;
+        }
+        dctx.cap = defer_cap;
+    }
+    auto run = [&](const bool defer) -> int {
+        if (defer) PNX_HIP(hipMemset(dctx.counters, 0, 2 * sizeof(int32_t)));
+        auto span = [&](int k, size_t &off, size_t &c) {
+            off = bounds[(size_t)k];
+            c = bounds[(size_t)k + 1] - off;
+        };
+        PipeOps ops;
+        ops.h2d = [&](int k, int slot, hipStream_t s) -> int {
+            size_t off, c;
+            span(k, off, c);
+            PNX_HIP(hipMemcpyAsync(slots[slot].ty, y + off * P.n_meas, c * P.n_meas * sizeof(T), hipMemcpyHostToDevice, s));
+            return PNX_OK;
+        };
+        ops.launch = [&](int k, int slot, hipStream_t s) -> int {
+            Slot &S = slots[slot];
+            size_t off, c;
+            span(k, off, c);
+            int r = PNX_OK;
+            if constexpr (F32)
+                if ((r = cvt(S.ty, S.y, c * P.n_meas, s))) return r;
+            if (defer) {
+                NnlsDefer d = dctx;
+                d.base = (int64_t)off;
+                r = nnls_blk_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s, &d);
+            } else {
+                r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
+            }
+            if (r) return r;
+            if constexpr (F32)
+                if ((r = cvt(S.c, S.tc, c * P.n_bins, s)) || (r = cvt(S.r, S.tr, c, s))) return r;
+            return PNX_OK;
+        };
+        ops.touch = [&](int k) {
+            size_t off, c;
+            span(k, off, c);
+            touch_pages(coeff + off * P.n_bins, c * P.n_bins * sizeof(T));
+            touch_pages(rnorm + off, c * sizeof(T));
+            if (status) touch_pages(status + off, c);
+            if (iters) touch_pages(iters + off, c * sizeof(int32_t));
+        };
+        ops.d2h = [&](int k, int slot, hipStream_t s) -> int {
+            Slot &S = slots[slot];
+            size_t off, c;
+            span(k, off, c);
+            PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, S.tc, c * P.n_bins * sizeof(T), hipMemcpyDeviceToHost, s));
+            PNX_HIP(hipMemcpyAsync(rnorm + off, S.tr, c * sizeof(T), hipMemcpyDeviceToHost, s));
+            if (status) PNX_HIP(hipMemcpyAsync(status + off, S.s, c, hipMemcpyDeviceToHost, s));
+            if (iters) PNX_HIP(hipMemcpyAsync(iters + off, S.i, c * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            return PNX_OK;
+        };
+        int r = run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+        if (r || !defer) return r;
+        int32_t cnt[2] = {0, 0};
+        PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+        const int n = cnt[0];
+        if (n > defer_cap) return kDeferOverflow;  // more handed-over voxels than the side buffer holds: run again, one pass per chunk
+        if (n == 0) return PNX_OK;
+        DevBuf side;
+        double *sc = nullptr, *sr = nullptr;
+        int8_t *ss = nullptr;
+        int32_t *si = nullptr, *iota = nullptr;
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)side.p;
+            sc = (double *)c.take((size_t)n * P.n_bins * sizeof(double));
+            sr = (double *)c.take((size_t)n * sizeof(double));
+            ss = (int8_t *)c.take((size_t)n);
+            si = (int32_t *)c.take((size_t)n * sizeof(int32_t));
+            iota = (int32_t *)c.take((size_t)n * sizeof(int32_t));
+            if (pass == 0 && (r = side.alloc(c.off))) return r;
+        }
+        std::vector<int32_t> idx((size_t)n), where((size_t)n), hi((size_t)n);
+        for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+        PNX_HIP(hipMemcpy(iota, idx.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        if ((r = nnls_redo_device(&P, n, dctx.y_side, max_iter, sc, sr, ss, si, iota, dctx.counters, st))) return r;
+        PNX_HIP(hipStreamSynchronize(st));
+        std::vector<double> hc((size_t)n * P.n_bins), hr((size_t)n);
+        std::vector<int8_t> hs((size_t)n);
+        PNX_HIP(hipMemcpy(hc.data(), sc, hc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hr.data(), sr, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hs.data(), ss, hs.size(), hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hi.data(), si, hi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(where.data(), dctx.bail, where.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {  // (T) of a double rounds to nearest, as the device's narrowing copy does
+            const size_t v = (size_t)where[(size_t)i];
+            for (int j = 0; j < P.n_bins; ++j) coeff[v * P.n_bins + j] = (T)hc[(size_t)i * P.n_bins + j];
+            rnorm[v] = (T)hr[(size_t)i];
+            if (status) status[v] = hs[(size_t)i];
+            if (iters) iters[v] = hi[(size_t)i];
+        }
         return PNX_OK;
     };
-    ops.launch = [&](int k, int slot, hipStream_t s) -> int {
-        Slot &S = slots[slot];
-        size_t off, c;
-        span(k, off, c);
-        int r = PNX_OK;
-        if constexpr (F32)
-            if ((r = cvt(S.ty, S.y, c * P.n_meas, s))) return r;
-        r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
-        if (r) return r;
-        if constexpr (F32)
-            if ((r = cvt(S.c, S.tc, c * P.n_bins, s)) || (r = cvt(S.r, S.tr, c, s))) return r;
-        return PNX_OK;
-    };
-    ops.touch = [&](int k) {
-        size_t off, c;
-        span(k, off, c);
-        touch_pages(coeff + off * P.n_bins, c * P.n_bins * sizeof(T));
-        touch_pages(rnorm + off, c * sizeof(T));
-        if (status) touch_pages(status + off, c);
-        if (iters) touch_pages(iters + off, c * sizeof(int32_t));
-    };
-    ops.d2h = [&](int k, int slot, hipStream_t s) -> int {
-        Slot &S = slots[slot];
-        size_t off, c;
-        span(k, off, c);
-        PNX_HIP(hipMemcpyAsync(coeff + off * P.n_bins, S.tc, c * P.n_bins * sizeof(T), hipMemcpyDeviceToHost, s));
-        PNX_HIP(hipMemcpyAsync(rnorm + off, S.tr, c * sizeof(T), hipMemcpyDeviceToHost, s));
-        if (status) PNX_HIP(hipMemcpyAsync(status + off, S.s, c, hipMemcpyDeviceToHost, s));
-        if (iters) PNX_HIP(hipMemcpyAsync(iters + off, S.i, c * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        return PNX_OK;
-    };
-    return run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+    rc = run(can_defer);
+    if (rc == kDeferOverflow) rc = run(false);
+    return rc;
 }
 
 extern "C" {

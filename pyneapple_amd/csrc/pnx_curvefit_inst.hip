@@ -45,6 +45,11 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, block, shmem);
     if (e != hipSuccess || occ < 1) return set_error(PNX_ERR_HIP, "occupancy query failed (shmem=%zu): %s", shmem, hipGetErrorString(e));
+    // A streamed launch shares the chip with its own uploads and downloads (the runtime's copy kernels), the covariance
+    // epilogue and the float32 conversions, all of which must become resident WHILE it runs -- the kernel waits for their
+    // data.  One block per CU leaves at least 132 of the 512 registers per lane free on every SIMD (two blocks of the
+    // 246-register mono kernel would leave 20, and the uploads would wait for the kernel that waits for them).
+    if (STREAM && occ > 1) occ = 1;
     long long want = (args.n_vox + block - 1) / block;
     long long cap = (long long)occ * device_cus;
     int grid = (int)(want < cap ? want : cap);

@@ -46,8 +46,18 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
                      int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream);
 bool nnls_blk_applicable(const NnlsPlanData *P);
 int nnls_blk_plan_init(NnlsPlanData *P);
+// Deferred hand-over (host-array calls made of several chunks, pnx_api.hip): the block kernel appends the voxels it hands over
+// to `bail` with their index within the whole call (`base` + index within this chunk), a gather keeps their signal rows in
+// `y_side`, and the caller solves them in one pass at the end instead of one pass per chunk.
+struct NnlsDefer {
+    int32_t *counters;  // device: [0] voxels handed over so far, [1] signal rows gathered so far
+    int32_t *bail;      // device: indices within the call, room for every voxel of the call
+    double *y_side;     // device: (cap, n_meas) signal rows of the first `cap` handed-over voxels
+    int cap;
+    int64_t base;       // first voxel of this chunk within the call
+};
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
-                          int8_t *status_d, int32_t *iters_d, hipStream_t stream);
+                          int8_t *status_d, int32_t *iters_d, hipStream_t stream, const NnlsDefer *defer = nullptr);
 int nnls_aty_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, double *aty_d, hipStream_t stream);
 int nnls_build_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis);
 

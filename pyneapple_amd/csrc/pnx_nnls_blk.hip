@@ -1005,17 +1005,32 @@ int nnls_blk_plan_init(NnlsPlanData *P) {
     return PNX_OK;
 }
 
+// Copies the signal rows of the voxels handed over since the last call into the deferred list's dense side buffer (one
+// block; a chunk hands over a few dozen voxels).  counters[0] = voxels handed over so far, counters[1] = rows copied so far.
+__global__ void __launch_bounds__(256) bail_gather_kernel(int32_t *counters, const int32_t *bail, const double *y, long long base,
+                                                          int n_meas, double *y_side, int cap) {
+    const int n = counters[0] < cap ? counters[0] : cap, p = counters[1];
+    for (long long e = (long long)p * n_meas + threadIdx.x; e < (long long)n * n_meas; e += blockDim.x) {
+        const int i = (int)(e / n_meas), j = (int)(e % n_meas);
+        y_side[e] = y[((long long)bail[i] - base) * n_meas + j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n > p) counters[1] = n;
+}
+
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
-                          int8_t *status_d, int32_t *iters_d, hipStream_t stream) {
+                          int8_t *status_d, int32_t *iters_d, hipStream_t stream, const NnlsDefer *defer) {
     if (n_vox <= 0) return PNX_OK;
     if (n_vox >= (int64_t)1 << 31) return set_error(PNX_ERR_INVALID, "n_vox=%lld: at most 2^31 - 1 voxels per call", (long long)n_vox);
-    if ((size_t)n_vox > P->blk_bail_cap) {  // the hand-over list holds every voxel of a call in the worst case
-        (void)hipFree(P->blk_bail);  // synchronises: no earlier solve of this plan is still using it
-        P->blk_bail = nullptr;
-        P->blk_bail_cap = (size_t)n_vox;
-        PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
+    if (!defer) {
+        if ((size_t)n_vox > P->blk_bail_cap) {  // the hand-over list holds every voxel of a call in the worst case
+            (void)hipFree(P->blk_bail);  // synchronises: no earlier solve of this plan is still using it
+            P->blk_bail = nullptr;
+            P->blk_bail_cap = (size_t)n_vox;
+            PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
+        }
+        PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
     }
-    PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
     // launches of kAtyChunk voxels (256 per resident wave keep the drain tail small)
     for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
         const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
@@ -1028,9 +1043,9 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         a.G = P->G;
         a.Bp = P->Bp;
         a.Mglob = P->Mblk;
-        a.n_bail = P->blk_bail;
-        a.bail = P->blk_bail + 1;
-        a.vox_base = off;
+        a.n_bail = defer ? defer->counters : P->blk_bail;
+        a.bail = defer ? defer->bail : P->blk_bail + 1;
+        a.vox_base = (defer ? defer->base : 0) + off;
         a.queue = P->queue;
         a.n_vox = c;
         a.n_meas = P->n_meas;
@@ -1047,6 +1062,15 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
     }
     // voxels whose passive set outgrew this kernel (about one in 10^4 on the reference workload, and the slowest ones: a single
     // launch for the whole call, so that their long solves overlap): the general kernel, from scratch
+    if (defer) {
+        // a host-array call made of several chunks: this chunk's handed-over voxels keep their signal rows in the side buffer,
+        // and ONE pass at the end of the call solves them all (each such pass costs ~8 ms whatever the number of voxels:
+        // they are the longest solves there are)
+        hipLaunchKernelGGL(bail_gather_kernel, dim3(1), dim3(256), 0, stream, defer->counters, defer->bail, y_d, (long long)defer->base,
+                           P->n_meas, defer->y_side, defer->cap);
+        PNX_HIPB(hipGetLastError());
+        return PNX_OK;
+    }
     return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk_bail + 1, P->blk_bail, stream);
 }
 

@@ -349,7 +349,7 @@ def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
 
 @pytest.mark.parametrize("model,n_b,dtype,pcov", [("tri_reduced", 32, np.float64, True), ("bi_reduced", 23, np.float64, False),
                                                   ("tri_reduced", 32, np.float32, True), ("mono", 16, np.float32, False)])
-def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, model, n_b, dtype, pcov):
+def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, capfd, model, n_b, dtype, pcov):
     """Host arrays with shared p0 / bounds run as ONE persistent kernel that waits at an upload watermark and hands finished
     granules to the download while it is still fitting (pnx_api.hip curvefit_streamed).  Ragged granules, upload pieces that
     do not line up with granules, odd n_b (no LDS-DMA refill) and the float32 entry point must all return, bit for bit,
@@ -365,6 +365,8 @@ def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, model, n_
     monkeypatch.setenv("PNX_HOST_STREAM", "0")
     ring = gpu.curvefit(model, b, y, p0, lo, hi, want_pcov=pcov)
     monkeypatch.setenv("PNX_HOST_STREAM", "1")
+    monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    capfd.readouterr()
     for shift, piece, touchers in (("10", "1024", "2"), ("12", "3000", "0"), ("11", "65536", "3")):
         monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", shift)
         monkeypatch.setenv("PNX_STREAM_IN_CHUNK", piece)
@@ -373,6 +375,9 @@ def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, model, n_
         for k in ("popt", "pcov", "status", "nfev", "cost"):
             if ring[k] is not None:
                 np.testing.assert_array_equal(st[k], ring[k], err_msg=f"{k} shift={shift}")
+    err = capfd.readouterr().err
+    assert err.count("[pnx stream]") >= 3 and "TIMED OUT" not in err and "timed out" not in err  # streamed, no fall-back
+    monkeypatch.delenv("PNX_HOST_TRACE")
     assert (ring["status"] > 0).mean() > 0.99
     if dtype is np.float64:
         dev = torch.device("cuda", 0)

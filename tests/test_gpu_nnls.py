@@ -176,6 +176,37 @@ def test_full_size_kkt_c4(gpu):
         torch.testing.assert_close(rnorm[bad], torch.linalg.norm(y[bad], dim=1))
 
 
+def test_host_chunks_defer_the_hand_over_pass(gpu, monkeypatch):
+    """Host arrays in several chunks: the block kernel's handed-over voxels (passive set beyond 128 positions) are solved in
+    ONE pass at the end of the call and patched into the result arrays.  Same bits as the single-chunk call (hand-over pass
+    inside it), as the per-chunk passes (PNX_NNLS_DEFER_CAP=0), and as the overflow path (side buffer too small -> the call
+    runs again with per-chunk passes); float32 storage likewise."""
+    import torch
+
+    from pyneapple_amd import synth
+
+    _, basis, reg = synth.nnls_matrices(32)
+    _, yt = synth.make_torch_rows("tri_reduced", 0, 1 << 14, 32, torch.device("cuda", 0), sigma=0.01, scale=1000.0)
+    y = yt.cpu().numpy()
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    one = plan.solve(y, 250)
+    handed_over = np.flatnonzero((one["coefficients"] > 0).sum(axis=1) > 128)
+    assert handed_over.size >= 1  # the sample holds such voxels (tests/test_gpu_parity_large.py compares them with the oracle)
+    one32 = plan.solve(y.astype(np.float32), 250)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "3000")  # six ragged chunks
+    for cap in ("16384", "0", str(max(1, handed_over.size - 1))):
+        monkeypatch.setenv("PNX_NNLS_DEFER_CAP", cap)
+        many = plan.solve(y, 250)
+        for k in ("coefficients", "residual", "status", "iters"):
+            np.testing.assert_array_equal(many[k], one[k], err_msg=f"{k} cap={cap}")
+    monkeypatch.setenv("PNX_NNLS_DEFER_CAP", "16384")
+    many32 = plan.solve(y.astype(np.float32), 250)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many32[k], one32[k], err_msg=f"{k} float32")
+    plan.close()
+
+
 def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
     """Chunked, pipelined host staging (solves in order on one stream) returns the single-chunk results."""
     from pyneapple_amd import synth
