@@ -209,11 +209,11 @@ class CurvefitLeg:
 
     def host_mode(self, reps=None):
         """The same fit through PNX_MEM_HOST: numpy signal in, numpy popt / pcov / status / nfev / cost out (PCIe inclusive).
-        Two timed calls for the big volumes, six for a call of a few ms (C1 / C2: one slow call -- the box sometimes takes
-        12 ms instead of 4.5 for C2 right after another leg's buffers were released -- would otherwise be half the figure);
-        the figure is the median, every call is in ms_reps."""
+        Three timed calls for the big volumes, six for a call of a few ms; the figure is the median and every call is in
+        ms_reps (one call in a few is slow on the box right after another leg's buffers were released: 59 instead of 39 ms
+        for C3, 12 instead of 4.5 ms for C2)."""
         if reps is None:
-            reps = 2 if self.n_vox >= (1 << 21) else 6
+            reps = 3 if self.n_vox >= (1 << 21) else 6
         y = self.y.cpu().numpy()
         kw = dict(max_nfev=250, ftol=1e-8, jac=self.jac, want_pcov=self.want_pcov, device=self.device.index)
         r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)  # warm-up (slots, first-touch)
@@ -230,7 +230,7 @@ class CurvefitLeg:
                 "unit": "voxels/s", "ms_per_step": dt * 1e3, "ms_reps": [t * 1e3 for t in ts], "h2d_bytes": int(y.nbytes), "d2h_bytes": int(d2h),
                 "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps, "equals_device_resident_result": same}
 
-    def host_mode_f32(self, reps=2):
+    def host_mode_f32(self, reps=3):
         """BASELINE's "fp32" configuration as a Pyneapple user runs it: float32 signal in, float32 popt / pcov / cost out through
         pnx_curvefit_batch_f32 (fp64 arithmetic on the widened values; half of the PCIe bytes of host_mode)."""
         y = self.y.cpu().numpy().astype(np.float32)
@@ -242,11 +242,11 @@ class CurvefitLeg:
             t = time.perf_counter()
             r = self.api.curvefit(self.model, self.b, y, self.p0, self.lo, self.hi, **kw)
             ts.append(time.perf_counter() - t)
-        dt = float(np.mean(ts))
+        dt = float(np.median(ts))
         d2h = sum(a.nbytes for a in r.values() if a is not None)
         return {"workload": "same volume as float32 numpy arrays in and out (pnx_curvefit_batch_f32, PNX_MEM_HOST)",
                 "value": self.n_vox / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "h2d_bytes": int(y.nbytes),
-                "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps,
+                "d2h_bytes": int(d2h), "pcie_GBps": (y.nbytes + d2h) / dt / 1e9, "steps": reps, "ms_reps": [t * 1e3 for t in ts],
                 "result_dtype": str(r["popt"].dtype), "converged_frac": float((r["status"] > 0).mean())}
 
     def cpu_baseline(self):
