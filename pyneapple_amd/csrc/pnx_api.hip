@@ -1260,6 +1260,190 @@ int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int m
     return nnls_solve<float>(plan, n_vox, y, max_iter, coeff, rnorm, status, iters, mem, stream);
 }
 
+// Host arrays in, peak tables out: the chunk ring of nnls_solve with the peak analysis behind every chunk's solve (the chunk's
+// spectra never leave the device) and the same deferred hand-over -- the handed-over voxels' spectra are solved in one pass at
+// the end, analysed, and their rows of the peak tables patched on the host.
+static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
+                                 double height, int regularized, double rel_height, int max_peaks, int32_t *n_peaks,
+                                 double *d_values, double *f_values, int n_cut, const double *cutoffs_host, double *d_cut,
+                                 double *f_cut, double *rnorm, int8_t *status, int32_t *iters, hipStream_t st) {
+    NnlsPlanData &P = plan->d;
+    if (max_peaks > 0 && (!d_values || !f_values)) return set_error(PNX_ERR_INVALID, "d_values / f_values are NULL");
+    if (n_cut > 0 && (!cutoffs_host || !d_cut || !f_cut)) return set_error(PNX_ERR_INVALID, "cutoffs / d_cut / f_cut are NULL");
+    const size_t nv = (size_t)n_vox;
+    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 3 << 18, 1024, 1 << 22);
+    const int n_chunks = (int)((nv + chunk - 1) / chunk);
+    const int n_slots = n_chunks < 3 ? n_chunks : 3;
+    const size_t cap = nv < chunk ? nv : chunk;
+    const size_t mp = (size_t)(max_peaks > 0 ? max_peaks : 1), nc = (size_t)(n_cut > 0 ? n_cut : 1);
+    int rc;
+    struct Out {  // device buffers of one batch of voxels: solver outputs + peak tables
+        double *spec = nullptr, *r = nullptr, *d = nullptr, *f = nullptr, *dc = nullptr, *fc = nullptr;
+        int8_t *s = nullptr;
+        int32_t *i = nullptr, *np = nullptr;
+        void carve(Carver &c, size_t n, int n_bins, size_t mp, size_t nc) {
+            spec = (double *)c.take(n * n_bins * 8);
+            r = (double *)c.take(n * 8);
+            d = (double *)c.take(n * mp * 8);
+            f = (double *)c.take(n * mp * 8);
+            dc = (double *)c.take(n * nc * 8);
+            fc = (double *)c.take(n * nc * 8);
+            i = (int32_t *)c.take(n * 4);
+            np = (int32_t *)c.take(n * 4);
+            s = (int8_t *)c.take(n);
+        }
+    };
+    struct Slot {
+        DevBuf slab;
+        double *y = nullptr;
+        Out o;
+    };
+    std::vector<Slot> slots((size_t)n_slots);
+    for (auto &S : slots)
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)S.slab.p;
+            S.y = (double *)c.take(cap * P.n_meas * 8);
+            S.o.carve(c, cap, P.n_bins, mp, nc);
+            if (pass == 0 && (rc = S.slab.alloc(c.off))) return rc;
+        }
+    auto analyse = [&](size_t n, const Out &o, hipStream_t s) -> int {
+        return pnx_nnls_spectrum_peaks_f64((int64_t)n, P.n_bins, o.spec, bins_host, height, regularized, rel_height, max_peaks, o.np, o.d,
+                                           o.f, n_cut, cutoffs_host, o.dc, o.fc, PNX_MEM_DEVICE, P.device, s);
+    };
+    constexpr int kDeferOverflow = -1001;
+    const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
+    const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
+    DevBuf dslab;
+    NnlsDefer dctx{};
+    if (can_defer) {
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)dslab.p;
+            dctx.counters = (int32_t *)c.take(2 * sizeof(int32_t));
+            dctx.bail = (int32_t *)c.take(nv * sizeof(int32_t));
+            dctx.y_side = (double *)c.take((size_t)defer_cap * P.n_meas * sizeof(double));
+            if (pass == 0 && (rc = dslab.alloc(c.off))) return rc;
+        }
+        dctx.cap = defer_cap;
+    }
+    auto run = [&](const bool defer) -> int {
+        if (defer) PNX_HIP(hipMemset(dctx.counters, 0, 2 * sizeof(int32_t)));
+        auto span = [&](int k, size_t &off, size_t &c) {
+            off = (size_t)k * chunk;
+            c = (nv - off) < chunk ? (nv - off) : chunk;
+        };
+        PipeOps ops;
+        ops.h2d = [&](int k, int slot, hipStream_t s) -> int {
+            size_t off, c;
+            span(k, off, c);
+            PNX_HIP(hipMemcpyAsync(slots[(size_t)slot].y, y + off * P.n_meas, c * P.n_meas * 8, hipMemcpyHostToDevice, s));
+            return PNX_OK;
+        };
+        ops.launch = [&](int k, int slot, hipStream_t s) -> int {
+            Slot &S = slots[(size_t)slot];
+            size_t off, c;
+            span(k, off, c);
+            int r;
+            if (defer) {
+                NnlsDefer d = dctx;
+                d.base = (int64_t)off;
+                r = nnls_blk_solve_device(&P, (int64_t)c, S.y, max_iter, S.o.spec, S.o.r, S.o.s, S.o.i, s, &d);
+            } else {
+                r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.o.spec, S.o.r, S.o.s, S.o.i, s);
+            }
+            return r ? r : analyse(c, S.o, s);
+        };
+        ops.touch = [&](int k) {
+            size_t off, c;
+            span(k, off, c);
+            touch_pages(rnorm + off, c * 8);
+            if (status) touch_pages(status + off, c);
+            if (iters) touch_pages(iters + off, c * 4);
+            if (n_peaks) touch_pages(n_peaks + off, c * 4);
+            if (max_peaks > 0) {
+                touch_pages(d_values + off * max_peaks, c * max_peaks * 8);
+                touch_pages(f_values + off * max_peaks, c * max_peaks * 8);
+            }
+            if (n_cut > 0) {
+                touch_pages(d_cut + off * n_cut, c * n_cut * 8);
+                touch_pages(f_cut + off * n_cut, c * n_cut * 8);
+            }
+        };
+        ops.d2h = [&](int k, int slot, hipStream_t s) -> int {
+            const Out &o = slots[(size_t)slot].o;
+            size_t off, c;
+            span(k, off, c);
+            PNX_HIP(hipMemcpyAsync(rnorm + off, o.r, c * 8, hipMemcpyDeviceToHost, s));
+            if (status) PNX_HIP(hipMemcpyAsync(status + off, o.s, c, hipMemcpyDeviceToHost, s));
+            if (iters) PNX_HIP(hipMemcpyAsync(iters + off, o.i, c * 4, hipMemcpyDeviceToHost, s));
+            if (n_peaks) PNX_HIP(hipMemcpyAsync(n_peaks + off, o.np, c * 4, hipMemcpyDeviceToHost, s));
+            if (max_peaks > 0) {
+                PNX_HIP(hipMemcpyAsync(d_values + off * max_peaks, o.d, c * max_peaks * 8, hipMemcpyDeviceToHost, s));
+                PNX_HIP(hipMemcpyAsync(f_values + off * max_peaks, o.f, c * max_peaks * 8, hipMemcpyDeviceToHost, s));
+            }
+            if (n_cut > 0) {
+                PNX_HIP(hipMemcpyAsync(d_cut + off * n_cut, o.dc, c * n_cut * 8, hipMemcpyDeviceToHost, s));
+                PNX_HIP(hipMemcpyAsync(f_cut + off * n_cut, o.fc, c * n_cut * 8, hipMemcpyDeviceToHost, s));
+            }
+            return PNX_OK;
+        };
+        int r = run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+        if (r || !defer) return r;
+        int32_t cnt[2] = {0, 0};
+        PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+        const size_t n = (size_t)cnt[0];
+        if ((int)n > defer_cap) return kDeferOverflow;
+        if (n == 0) return PNX_OK;
+        DevBuf side;
+        Out o;
+        int32_t *iota = nullptr;
+        for (int pass = 0; pass < 2; ++pass) {
+            Carver c;
+            c.base = (char *)side.p;
+            o.carve(c, n, P.n_bins, mp, nc);
+            iota = (int32_t *)c.take(n * 4);
+            if (pass == 0 && (r = side.alloc(c.off))) return r;
+        }
+        std::vector<int32_t> idx(n), where(n), hi(n), hn(n);
+        for (size_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
+        PNX_HIP(hipMemcpy(iota, idx.data(), n * 4, hipMemcpyHostToDevice));
+        if ((r = nnls_redo_device(&P, (int64_t)n, dctx.y_side, max_iter, o.spec, o.r, o.s, o.i, iota, dctx.counters, st))) return r;
+        if ((r = analyse(n, o, st))) return r;
+        PNX_HIP(hipStreamSynchronize(st));
+        std::vector<double> hr(n), hd(n * mp), hf(n * mp), hdc(n * nc), hfc(n * nc);
+        std::vector<int8_t> hs(n);
+        PNX_HIP(hipMemcpy(hr.data(), o.r, n * 8, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hs.data(), o.s, n, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hi.data(), o.i, n * 4, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hn.data(), o.np, n * 4, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hd.data(), o.d, n * mp * 8, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hf.data(), o.f, n * mp * 8, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hdc.data(), o.dc, n * nc * 8, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(hfc.data(), o.fc, n * nc * 8, hipMemcpyDeviceToHost));
+        PNX_HIP(hipMemcpy(where.data(), dctx.bail, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            const size_t v = (size_t)where[i];
+            rnorm[v] = hr[i];
+            if (status) status[v] = hs[i];
+            if (iters) iters[v] = hi[i];
+            if (n_peaks) n_peaks[v] = hn[i];
+            for (int j = 0; j < max_peaks; ++j) {
+                d_values[v * max_peaks + j] = hd[i * mp + j];
+                f_values[v * max_peaks + j] = hf[i * mp + j];
+            }
+            for (int j = 0; j < n_cut; ++j) {
+                d_cut[v * n_cut + j] = hdc[i * nc + j];
+                f_cut[v * n_cut + j] = hfc[i * nc + j];
+            }
+        }
+        return PNX_OK;
+    };
+    rc = run(can_defer);
+    if (rc == kDeferOverflow) rc = run(false);
+    return rc;
+}
+
 int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
                              double height, int regularized, double rel_height, int max_peaks, int32_t *n_peaks,
                              double *d_values, double *f_values, int n_cut, const double *cutoffs_host, double *d_cut,
@@ -1273,6 +1457,9 @@ int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y
     hipStream_t st = (hipStream_t)stream;
     if (max_iter <= 0) max_iter = 3 * P.n_bins;
     std::lock_guard<std::mutex> plan_lock(plan->mu);
+    if (mem == PNX_MEM_HOST && env_int("PNX_NNLS_PEAKS_RING", 1, 0, 1))
+        return nnls_solve_peaks_host(plan, n_vox, y, max_iter, bins_host, height, regularized, rel_height, max_peaks, n_peaks, d_values,
+                                     f_values, n_cut, cutoffs_host, d_cut, f_cut, rnorm, status, iters, st);
     // spectra of one chunk live in device scratch only: solve -> peak analysis -> next chunk
     const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 20, 1024, 1 << 22);
     const size_t nv = (size_t)n_vox, cap = nv < chunk ? nv : chunk;

@@ -207,6 +207,39 @@ def test_host_chunks_defer_the_hand_over_pass(gpu, monkeypatch):
     plan.close()
 
 
+def test_peak_tables_from_host_arrays_in_chunks(gpu, monkeypatch):
+    """pnx_nnls_solve_peaks_f64 on host arrays: chunk ring with the peak analysis behind every chunk's solve and the deferred
+    hand-over (the handed-over voxels' peak rows are patched at the end).  Equal to the one-chunk call, to the per-chunk
+    hand-over, to the old serial loop, and to solve() followed by the peak analysis of the returned spectra."""
+    import torch
+
+    from pyneapple_amd import synth
+
+    bins, basis, reg = synth.nnls_matrices(32)
+    _, yt = synth.make_torch_rows("tri_reduced", 0, 1 << 14, 32, torch.device("cuda", 0), sigma=0.01, scale=1000.0)
+    y = yt.cpu().numpy()
+    cuts = [(0.0008, 0.003), (0.003, 0.02), (0.02, 0.5)]
+    kw = dict(max_iter=250, height=0.1, regularized=True, max_peaks=8, cutoffs=cuts)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    full = plan.solve(y, 250)
+    assert ((full["coefficients"] > 0).sum(axis=1) > 128).any()
+    ref = gpu.spectrum_peaks(full["coefficients"], bins, height=0.1, regularized=True, max_peaks=8, cutoffs=cuts)
+    monkeypatch.setenv("PNX_NNLS_PEAKS_CHUNK", str(1 << 20))
+    one = plan.solve_peaks(y, bins, **kw)
+    for k in ("n_peaks", "d_values", "f_values", "d_cut", "f_cut"):
+        np.testing.assert_array_equal(one[k], ref[k], err_msg=k)
+    np.testing.assert_array_equal(one["residual"], full["residual"])
+    monkeypatch.setenv("PNX_NNLS_PEAKS_CHUNK", "3000")
+    for cap, ring in (("16384", "1"), ("0", "1"), ("16384", "0")):
+        monkeypatch.setenv("PNX_NNLS_DEFER_CAP", cap)
+        monkeypatch.setenv("PNX_NNLS_PEAKS_RING", ring)
+        many = plan.solve_peaks(y, bins, **kw)
+        for k in one:
+            np.testing.assert_array_equal(many[k], one[k], err_msg=f"{k} cap={cap} ring={ring}")
+    plan.close()
+
+
 def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
     """Chunked, pipelined host staging (solves in order on one stream) returns the single-chunk results."""
     from pyneapple_amd import synth
