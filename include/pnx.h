@@ -12,9 +12,10 @@
  *   - Every function returns 0 on success or a negative pnx_error; the message of the last
  *     error of the calling thread is available through pnx_last_error().
  *   - `mem` says where the *per-voxel* arrays live: PNX_MEM_HOST (pageable host memory; the library
- *     streams chunks of voxels through device slots on its own streams and helper threads -- copies
- *     in, kernels and copies out overlap -- and returns when every result is in place; `stream` is
- *     synchronised on entry) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
+ *     moves the volume over PCIe on its own streams and helper threads while the kernels run -- a curve fit
+ *     with shared p0 / bounds as ONE kernel that waits at an upload watermark and whose finished voxels are
+ *     downloaded while it is still fitting, everything else as chunks through a ring of device slots --
+ *     and returns when every result is in place; `stream` is synchronised on entry) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
  *     enqueues work on `stream` and returns; the caller synchronises).  Small shared inputs
  *     (b-values, shared p0/bounds, basis, regulariser) are ALWAYS host pointers.
  *   - Thread safety: every entry point may be called from several host threads (e.g. one per
@@ -24,7 +25,7 @@
  *   - Throughput: a curve-fit batch ends in a tail -- a few voxels that need ten times the average number of evaluations
  *     keep their lanes busy after the work queue is empty (about 6 of 37 ms for 4 M triexp voxels).  Device-mode callers
  *     with independent batches should enqueue them on two or more streams: the next batch fills the idle SIMDs (the host
- *     mode does this with its own chunks).
+ *     mode pays one tail per call and downloads during it).
  *   - The caller allocates all outputs.  The library owns only device scratch.
  *   - Per-voxel numerical failure never produces an error code: it is reported in `status[]`
  *     with the reference's sentinel outputs (curvefit.py:308-317, nnls_solver.py:201-210).
