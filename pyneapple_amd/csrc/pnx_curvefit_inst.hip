@@ -63,12 +63,9 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
 
 template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
     if (args.ctl && args.phase != 2) {
-        // streamed launches exist for shared p0 / bounds with every parameter free (what the host path asks for)
-        constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
-        if constexpr (N == NP) {
-            if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
-        }
-        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch needs shared p0 / bounds and no fixed parameters");
+        // streamed launches exist for shared p0 / bounds (what the host path asks for), with or without fixed parameters
+        if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
+        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch needs shared p0 / bounds");
     }
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }

@@ -392,6 +392,37 @@ def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, capfd, mo
         np.testing.assert_array_equal(cost.cpu().numpy(), ring["cost"])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_streamed_host_path_with_fixed_parameters(gpu, monkeypatch, capfd, dtype):
+    """Shared p0 / bounds with fixed parameters (analytic Jacobian) also run as one streamed kernel: a shared fixed value, and
+    the per-voxel fixed map of SegmentedFitter's second step, which is uploaded piece by piece with the signal.  Same bits as
+    the chunk ring."""
+    from pyneapple_amd import synth
+
+    n_vox = 30000 + 11
+    b, y, P = synth.make_numpy("bi_reduced", n_vox, 24, sigma=0.01, seed=8)
+    y = y.astype(dtype)
+    names, p0s, los, his = synth.shared_arrays("bi_reduced")
+    free = [0, 2]  # f1, D2 free; D1 fixed
+    cases = [dict(fixed_idx=[1], fixed_vals=np.array([P["D1"].mean()]), jac="analytic"),
+             dict(fixed_idx=[1], fixed_vals=P["D1"][None, :].astype(dtype), jac="analytic")]
+    for kw in cases:
+        monkeypatch.setenv("PNX_HOST_STREAM", "0")
+        monkeypatch.delenv("PNX_HOST_TRACE", raising=False)
+        ring = gpu.curvefit("bi_reduced", b, y, p0s[free], los[free], his[free], **kw)
+        monkeypatch.setenv("PNX_HOST_STREAM", "1")
+        monkeypatch.setenv("PNX_HOST_TRACE", "1")
+        monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "11")
+        monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "3000")
+        capfd.readouterr()
+        st = gpu.curvefit("bi_reduced", b, y, p0s[free], los[free], his[free], **kw)
+        err = capfd.readouterr().err
+        assert "[pnx stream]" in err and "timed out" not in err
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            np.testing.assert_array_equal(st[k], ring[k], err_msg=k)
+        assert (ring["status"] > 0).mean() > 0.99
+
+
 def test_streamed_host_path_stalled_upload_falls_back(gpu, monkeypatch, capfd):
     """The streamed kernel's wait for the upload watermark is bounded: when the upload stalls for longer than the poll
     limit the lanes leave, the grid drains, and the call is run again through the chunk ring -- same results, no hang."""
