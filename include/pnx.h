@@ -13,7 +13,7 @@
  *     error of the calling thread is available through pnx_last_error().
  *   - `mem` says where the *per-voxel* arrays live: PNX_MEM_HOST (pageable host memory; the library
  *     moves the volume over PCIe on its own streams and helper threads while the kernels run -- a curve fit
- *     with shared p0 / bounds as ONE kernel that waits at an upload watermark and whose finished voxels are
+ *     as ONE kernel that waits at an upload watermark and whose finished voxels are
  *     downloaded while it is still fitting, everything else as chunks through a ring of device slots --
  *     and returns when every result is in place; `stream` is synchronised on entry) or PNX_MEM_DEVICE (pointers are HBM addresses on `device`; the call only
  *     enqueues work on `stream` and returns; the caller synchronises).  Small shared inputs
@@ -118,7 +118,7 @@ int pnx_last_error(char *buf, int n);
 int pnx_model_n_params(int model);
 
 /*
- * PNX_MEM_HOST curve-fit calls with shared p0 / bounds keep one device staging slab (the volume's signal and results,
+ * PNX_MEM_HOST curve-fit calls keep one device staging slab (the volume's signal and results,
  * up to PNX_STREAM_CACHE_MB, default 8192), a pinned control block and their streams per device for the next call.
  * This frees them; PNX_ERR_INVALID while such a call is running on the device.
  */

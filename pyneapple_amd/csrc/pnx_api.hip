@@ -466,8 +466,8 @@ struct AsyncBuf {
 // ---- host-pointer calls, streamed --------------------------------------------------------------------------------
 // The chunk ring above launches one persistent kernel per chunk, and every one of them ends in a drain tail (lanes whose
 // queue ran dry idle until the slowest voxel of their wave has converged): seven tails cost C3 about 10 ms of its 50.
-// With shared p0 / bounds (fixed parameters or not: a per-voxel fixed map is uploaded piece by piece like the signal) the whole
-// call is ONE kernel instead (CurvefitArgs::ctl):
+// The whole call is ONE kernel instead (CurvefitArgs::ctl; per-voxel start values, bounds and fixed maps are uploaded piece by
+// piece like the signal):
 //   IN    uploads the signal piece by piece and moves the kernel's watermark behind each piece (an 8-byte copy on the
 //         same stream, so the data is there before the watermark says so);
 //   the kernel's lanes pull voxels in ascending order and wait at the watermark; each wave counts itself out of a granule
@@ -570,12 +570,13 @@ struct StreamLease {
 
 template <typename T>
 static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double *bd, const T *y, const double *p0d,
-                             const double *lod, const double *hid, const double *fxd, const T *fixed_pv, T *popt, T *pcov,
-                             int8_t *status, int32_t *nfev, T *cost, int gshift, DeviceInfo *dev, int device,
-                             hipStream_t user_stream) {
+                             const double *lod, const double *hid, const T *p0_pv, const T *lo_pv, const T *hi_pv,
+                             const double *fxd, const T *fixed_pv, T *popt, T *pcov, int8_t *status, int32_t *nfev, T *cost,
+                             int gshift, DeviceInfo *dev, int device, hipStream_t user_stream) {
     constexpr bool F32 = sizeof(T) == 4;
     const int n = o->n_free, n_b = o->n_b;
     const int n_fpv = fixed_pv ? o->n_fixed : 0;  // per-voxel fixed maps (n_fixed, n_vox): uploaded piece by piece like the signal
+    const bool pv = p0_pv != nullptr;             // per-voxel p0 / bounds (n_free, n_vox) each: likewise
     const size_t G = (size_t)1 << gshift;
     const int n_gran = (int)((nv + G - 1) >> gshift);
     const size_t in_piece = (size_t)env_int("PNX_STREAM_IN_CHUNK", 1 << 17, 1024, 1 << 26);  // voxels per upload / watermark step
@@ -589,8 +590,8 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     // device: the whole volume's fp64 working set (+ the T-typed transfer buffers of the float32 entry point) + control block
     StreamLease lease(device);
     StreamRes &res = *lease.r;
-    double *dy = nullptr, *dpopt = nullptr, *dpcov = nullptr, *dcost = nullptr, *dfx = nullptr;
-    T *ty = nullptr, *tpopt = nullptr, *tpcov = nullptr, *tcost = nullptr, *tfx = nullptr;
+    double *dy = nullptr, *dpopt = nullptr, *dpcov = nullptr, *dcost = nullptr, *dfx = nullptr, *dp0 = nullptr, *dlo = nullptr, *dhi = nullptr;
+    T *ty = nullptr, *tpopt = nullptr, *tpcov = nullptr, *tcost = nullptr, *tfx = nullptr, *tp0 = nullptr, *tlo = nullptr, *thi = nullptr;
     int8_t *dstat = nullptr;
     int32_t *dnfev = nullptr;
     StreamCtl *ctl = nullptr;
@@ -605,6 +606,11 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
         };
         both(dy, ty, nv * n_b);
         if (n_fpv) both(dfx, tfx, nv * n_fpv);
+        if (pv) {
+            both(dp0, tp0, nv * n);
+            both(dlo, tlo, nv * n);
+            both(dhi, thi, nv * n);
+        }
         both(dpopt, tpopt, nv * n);
         if (pcov) both(dpcov, tpcov, nv * n * n);
         if (need_stat) dstat = (int8_t *)c.take(nv);
@@ -638,7 +644,8 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     sl.granule_shift = gshift;
     sl.spins = (unsigned int)env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 30);  // ~6 us per poll
     sl.phase = 1;
-    rc = curvefit_device(o, (int64_t)nv, bd, dy, p0d, lod, hid, n_fpv ? dfx : fxd, dpopt, dpcov, dstat, dnfev, dcost, dev, s_main, &sl);
+    rc = curvefit_device(o, (int64_t)nv, bd, dy, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, dpopt, dpcov, dstat,
+                         dnfev, dcost, dev, s_main, &sl);
     if (rc) return rc;
     const double t_launched = now();
 
@@ -680,6 +687,19 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
                 if constexpr (F32) {
                     int r = cvt(ty + v0 * n_b, dy + v0 * n_b, c * n_b, s_in);
                     if (r) return r;
+                }
+                if (pv) {  // parameter-major (n_free, n_vox) start values and bounds: one row slice per parameter and array
+                    const T *src[3] = {p0_pv, lo_pv, hi_pv};
+                    T *tdst[3] = {tp0, tlo, thi};
+                    double *ddst[3] = {dp0, dlo, dhi};
+                    for (int a3 = 0; a3 < 3; ++a3)
+                        for (int j = 0; j < n; ++j) {
+                            PNX_HIP(hipMemcpyAsync(tdst[a3] + j * nv + v0, src[a3] + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
+                            if constexpr (F32) {
+                                int r = cvt(tdst[a3] + j * nv + v0, ddst[a3] + j * nv + v0, c, s_in);
+                                if (r) return r;
+                            }
+                        }
                 }
                 for (int j = 0; j < n_fpv; ++j) {  // parameter-major (n_fixed, n_vox): one row slice per fixed parameter
                     PNX_HIP(hipMemcpyAsync(tfx + j * nv + v0, fixed_pv + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
@@ -729,7 +749,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
                 t_flag[g] = now();
                 const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
                 if (pcov) {
-                    int r = curvefit_device(o, (int64_t)c, bd, nullptr, p0d, lod, hid, n_fpv ? dfx : fxd, nullptr, dpcov + v0 * n * n,
+                    int r = curvefit_device(o, (int64_t)c, bd, nullptr, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, nullptr, dpcov + v0 * n * n,
                                             dstat + v0, nullptr, dcost + v0, dev, s_out, &s2);
                     if (r) return r;
                 }
@@ -856,12 +876,12 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         // granule = unit of the download (and of the completion flags): 256 Ki voxels for volumes of 2 Mi voxels and more,
         // 128 Ki below (C3: 2^17 41.4-44 ms, 2^18 40.6-43.9 ms, 2^16 and 2^19 42-45 ms; profiles/stream_sweep.py)
         const int gshift = env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
-        const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2 + (fpv ? o->n_fixed : 0)) * (F32 ? 12 : 8);
+        const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2 + (fpv ? o->n_fixed : 0) + (pv ? 3 * n : 0)) * (F32 ? 12 : 8);
         const size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
-        if (!pv && env_int("PNX_HOST_STREAM", 1, 0, 1) && nv > ((size_t)1 << gshift) && nv < ((size_t)1 << 31) &&
+        if (env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && nv > ((size_t)1 << gshift) && nv < ((size_t)1 << 31) &&
             nv * per_vox <= max_bytes) {
-            rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, fxd, fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift,
-                                      dev, device, (hipStream_t)stream);
+            rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, pv ? p0 : nullptr, pv ? lo : nullptr, pv ? hi : nullptr, fxd,
+                                      fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream);
             if (rc != kStreamRetry) return rc;
             static std::atomic<bool> warned(false);
             if (getenv("PNX_HOST_TRACE") || !warned.exchange(true))

@@ -63,9 +63,12 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
 
 template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
     if (args.ctl && args.phase != 2) {
-        // streamed launches exist for shared p0 / bounds (what the host path asks for), with or without fixed parameters
+        // streamed launch (host-array calls): shared p0 / bounds with any set of fixed parameters, per-voxel p0 / bounds with
+        // every parameter free (the combination of both stays with the chunk ring: it would double the build once more)
+        constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
         if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
-        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch needs shared p0 / bounds");
+        if constexpr (N == NP) return launch_one<MODEL, N, FD, true, T1, true>(args, cus, st);
+        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch: per-voxel p0 / bounds together with fixed parameters");
     }
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }

@@ -964,7 +964,9 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
                     for (int k = 0; k < N; ++k) blk[r][k] = live ? jr[CP(k)] : 0.0;  // factor column k = parameter CP(k)
                     blk[r][N] = rr;
                 }
+                CFSTAMP(1);  // rows of the block: exp, model, Jacobian row, J^T f (diagnostic builds: -DPNX_CF_STAMP)
                 qr_merge<N, kRowBlk>(Rn, qn, blk);
+                CFSTAMP(6);  // the sequential Householder merge of the block into R
             }
             cost_new *= 0.5;
         }
@@ -1197,8 +1199,8 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
     }
 #ifdef PNX_CF_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 3)
-        printf("CFSTAMP refill=%llu pass=%llu D+Blight=%llu final=%llu Bheavy=%llu C=%llu loop=%llu | iters=%llu idle_at_top=%.2f final=%.2f Bheavy=%.2f run=%.2f\n",
-               seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[7], cnt[1], (double)act[0] / cnt[0], (double)act[3] / cnt[3],
+        printf("CFSTAMP refill=%llu pass_rows=%llu pass_qr_merge=%llu D+Blight=%llu final=%llu Bheavy=%llu C=%llu loop=%llu | iters=%llu idle_at_top=%.2f final=%.2f Bheavy=%.2f run=%.2f\n",
+               seg[0], seg[1], seg[6], seg[2], seg[3], seg[4], seg[5], seg[7], cnt[1], (double)act[0] / cnt[0], (double)act[3] / cnt[3],
                (double)act[4] / cnt[4], (double)act[5] / cnt[5]);
 #endif
 }

@@ -423,6 +423,36 @@ def test_streamed_host_path_with_fixed_parameters(gpu, monkeypatch, capfd, dtype
         assert (ring["status"] > 0).mean() > 0.99
 
 
+def test_streamed_host_path_with_per_voxel_start_values_and_bounds(gpu, monkeypatch, capfd):
+    """Per-voxel p0 / bounds with every parameter free (what the reference's IDEAL fitter hands a solver plugin level by level):
+    the three parameter-major arrays are uploaded piece by piece in front of the same watermark as the signal."""
+    from pyneapple_amd import synth
+
+    n_vox = 25000 + 3
+    b, y, _ = synth.make_numpy("bi_reduced", n_vox, 24, sigma=0.01, seed=12)
+    rng = np.random.default_rng(12)
+    names, p0s, los, his = synth.shared_arrays("bi_reduced")
+    p0 = np.tile(p0s[:, None], (1, n_vox)) * rng.uniform(0.9, 1.1, (3, n_vox))
+    lo = np.tile(los[:, None], (1, n_vox)) * rng.uniform(0.8, 1.0, (3, n_vox))
+    hi = np.tile(his[:, None], (1, n_vox)) * rng.uniform(1.0, 1.2, (3, n_vox))
+    for dtype in (np.float64, np.float32):
+        yy = y.astype(dtype)
+        monkeypatch.setenv("PNX_HOST_STREAM", "0")
+        monkeypatch.delenv("PNX_HOST_TRACE", raising=False)
+        ring = gpu.curvefit("bi_reduced", b, yy, p0, lo, hi)
+        monkeypatch.setenv("PNX_HOST_STREAM", "1")
+        monkeypatch.setenv("PNX_HOST_TRACE", "1")
+        monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "11")
+        monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "3000")
+        capfd.readouterr()
+        st = gpu.curvefit("bi_reduced", b, yy, p0, lo, hi)
+        err = capfd.readouterr().err
+        assert "[pnx stream]" in err and "timed out" not in err
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            np.testing.assert_array_equal(st[k], ring[k], err_msg=f"{k} {dtype.__name__}")
+        assert (ring["status"] > 0).mean() > 0.99
+
+
 def test_streamed_host_path_stalled_upload_falls_back(gpu, monkeypatch, capfd):
     """The streamed kernel's wait for the upload watermark is bounded: when the upload stalls for longer than the poll
     limit the lanes leave, the grid drains, and the call is run again through the chunk ring -- same results, no hang."""
