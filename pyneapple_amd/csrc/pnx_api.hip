@@ -579,7 +579,10 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     const bool pv = p0_pv != nullptr;             // per-voxel p0 / bounds (n_free, n_vox) each: likewise
     const size_t G = (size_t)1 << gshift;
     const int n_gran = (int)((nv + G - 1) >> gshift);
-    const size_t in_piece = (size_t)env_int("PNX_STREAM_IN_CHUNK", 1 << 17, 1024, 1 << 26);  // voxels per upload / watermark step
+    // voxels per upload / watermark step.  Per-voxel p0 / bounds ride along as 3 n row slices per piece: at 128 Ki voxels those
+    // are 1 MB copies and the upload (1.57 GB for C3) runs at 36 GB/s and holds the kernel back (53-58 ms, the ring's 55); at
+    // 512 Ki 47-50 ms (profiles/stream_pv_probe.py)
+    const size_t in_piece = (size_t)env_int("PNX_STREAM_IN_CHUNK", p0_pv ? 1 << 19 : 1 << 17, 1024, 1 << 26);
     const int n_in = (int)((nv + in_piece - 1) / in_piece);
     const bool need_stat = status || pcov, need_cost = cost || pcov;
     const bool trace = getenv("PNX_HOST_TRACE") != nullptr;
