@@ -47,13 +47,25 @@ def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, 
     return o
 
 
+def _out(out, key, shape, dtype):
+    """A caller-provided result array (`out[key]`: C-contiguous, right shape and dtype -- e.g. a row range of a larger array
+    that several device shards fill) or a fresh one."""
+    a = None if out is None else out.get(key)
+    if a is None:
+        return np.empty(shape, dtype)
+    if a.shape != tuple(np.atleast_1d(shape)) or a.dtype != np.dtype(dtype) or not a.flags.c_contiguous:
+        raise ValueError(f"out[{key!r}] must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+    return a
+
+
 def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev=250, ftol=1e-8, xtol=1e-8,
-             gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0):
+             gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0, out=None):
     """Batched bounded NLLS on host (numpy) arrays.  Shapes as in include/pnx.h.
 
     A float32 signal array selects the fp32-storage entry point (pnx_curvefit_batch_f32: every data array float32 in
     and out, fp64 arithmetic on the device); anything else goes through pnx_curvefit_batch_f64.
     Returns dict(popt (n_free, n_vox), pcov (n_vox, n_free, n_free) | None, status int8, nfev int32, cost).
+    `out`: optional dict of preallocated result arrays ("pcov", "status", "nfev", "cost") to write into.
     """
     _lib.require_device()
     dt = np.float32 if getattr(y, "dtype", None) == np.float32 else np.float64
@@ -79,10 +91,10 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
     if fv is not None and fv.shape != ((o.n_fixed, n_vox) if fpv else (o.n_fixed,)):
         raise ValueError("fixed_vals has the wrong shape")
     popt = np.empty((n, n_vox), dt)
-    pcov = np.empty((n_vox, n, n), dt) if want_pcov else None
-    status = np.empty(n_vox, np.int8)
-    nfev = np.empty(n_vox, np.int32)
-    cost = np.empty(n_vox, dt)
+    pcov = _out(out, "pcov", (n_vox, n, n), dt) if want_pcov else None
+    status = _out(out, "status", (n_vox,), np.int8)
+    nfev = _out(out, "nfev", (n_vox,), np.int32)
+    cost = _out(out, "cost", (n_vox,), dt)
     fn = load().pnx_curvefit_batch_f32 if dt is np.float32 else load().pnx_curvefit_batch_f64
     check(fn(C.byref(o), n_vox, ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi), ptr(fv),
                                         ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost), MEM_HOST, device, None))
@@ -129,16 +141,17 @@ class NnlsPlan:
         check(load().pnx_nnls_plan_create(C.byref(self._h), self.n_meas, self.n_bins, ptr(basis), ptr(reg), n_reg,
                                           device))
 
-    def solve(self, y, max_iter=250):
+    def solve(self, y, max_iter=250, out=None):
+        """`out`: optional dict of preallocated result arrays ("coefficients", "residual", "status", "iters")."""
         dt = np.float32 if getattr(y, "dtype", None) == np.float32 else np.float64  # float32 in -> float32 out
         y = np.ascontiguousarray(np.atleast_2d(y), dt)
         n_vox = y.shape[0]
         if y.shape[1] != self.n_meas:
             raise ValueError(f"signal has {y.shape[1]} measurements, basis has {self.n_meas}")
-        coeff = np.empty((n_vox, self.n_bins), dt)
-        rnorm = np.empty(n_vox, dt)
-        status = np.empty(n_vox, np.int8)
-        iters = np.empty(n_vox, np.int32)
+        coeff = _out(out, "coefficients", (n_vox, self.n_bins), dt)
+        rnorm = _out(out, "residual", (n_vox,), dt)
+        status = _out(out, "status", (n_vox,), np.int8)
+        iters = _out(out, "iters", (n_vox,), np.int32)
         fn = load().pnx_nnls_solve_f32 if dt is np.float32 else load().pnx_nnls_solve_f64
         check(fn(self._h, n_vox, ptr(y), int(max_iter), ptr(coeff), ptr(rnorm), ptr(status),
                                         ptr(iters), MEM_HOST, None))
@@ -187,10 +200,10 @@ class NnlsPlan:
             pass
 
 
-def nnls(basis, reg, y, max_iter=250, device=0):
+def nnls(basis, reg, y, max_iter=250, device=0, out=None):
     plan = NnlsPlan(basis, reg, device)
     try:
-        return plan.solve(y, max_iter)
+        return plan.solve(y, max_iter, out=out)
     finally:
         plan.close()
 

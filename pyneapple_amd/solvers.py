@@ -295,6 +295,12 @@ class HipCurveFitSolver(CurveFitBase):
             return api.curvefit(self._kernel_model, xdata, ydata, p0, lo, hi, fixed_vals=fixed_vals,
                                 device=self.device, **kw)
         parts = _split(n_vox, n_dev)
+        # the shards write their voxel-major results straight into row ranges of the full arrays (pcov is 200 B per triexp voxel:
+        # concatenating it afterwards would cost more than the fit); popt is parameter-major and is joined afterwards
+        n = p0.shape[0]
+        dt = ydata.dtype
+        full = {"pcov": np.empty((n_vox, n, n), dt), "status": np.empty(n_vox, np.int8), "nfev": np.empty(n_vox, np.int32),
+                "cost": np.empty(n_vox, dt)}
 
         def work(k):
             a, b = parts[k]
@@ -305,15 +311,11 @@ class HipCurveFitSolver(CurveFitBase):
             pv = (np.ascontiguousarray(p0[:, sl]), np.ascontiguousarray(lo[:, sl]),
                   np.ascontiguousarray(hi[:, sl])) if per_voxel else (p0, lo, hi)
             return api.curvefit(self._kernel_model, xdata, ydata[sl], *pv, fixed_vals=fv,
-                                device=_shard_device(self.device, k), **kw)
+                                device=_shard_device(self.device, k), out={key: v[sl] for key, v in full.items()}, **kw)["popt"]
 
         with ThreadPoolExecutor(len(parts)) as ex:  # ctypes releases the GIL during the call
-            outs = list(ex.map(work, range(len(parts))))
-        return {"popt": np.concatenate([o["popt"] for o in outs], axis=1),
-                "pcov": np.concatenate([o["pcov"] for o in outs], axis=0),
-                "status": np.concatenate([o["status"] for o in outs]),
-                "nfev": np.concatenate([o["nfev"] for o in outs]),
-                "cost": np.concatenate([o["cost"] for o in outs])}
+            popts = list(ex.map(work, range(len(parts))))
+        return dict(full, popt=np.concatenate(popts, axis=1))
 
 
 class HipNNLSSolver(NNLSBase):
@@ -394,10 +396,12 @@ class HipNNLSSolver(NNLSBase):
             res = api.nnls(basis, reg, signal, max_iter, self.device)
         else:
             parts = _split(self.n_pixels, n_dev)
+            # every result is voxel-major: the shards write into row ranges of the full arrays (the spectra are 2 KB per voxel)
+            res = {"coefficients": np.empty((self.n_pixels, basis.shape[1]), signal.dtype), "residual": np.empty(self.n_pixels, signal.dtype),
+                   "status": np.empty(self.n_pixels, np.int8), "iters": np.empty(self.n_pixels, np.int32)}
             with ThreadPoolExecutor(len(parts)) as ex:
-                outs = list(ex.map(lambda k: api.nnls(basis, reg, signal[parts[k][0]:parts[k][1]], max_iter,
-                                                      _shard_device(self.device, k)), range(len(parts))))
-            res = {key: np.concatenate([o[key] for o in outs], axis=0) for key in outs[0]}
+                list(ex.map(lambda k: api.nnls(basis, reg, signal[parts[k][0]:parts[k][1]], max_iter, _shard_device(self.device, k),
+                                               out={key: v[parts[k][0]:parts[k][1]] for key, v in res.items()}), range(len(parts))))
         status = res["status"]
         self.pixel_results_ = PixelResultsView(
             res["coefficients"], None, status == 1,
