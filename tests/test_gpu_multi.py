@@ -39,6 +39,29 @@ def test_curvefit_abi_from_four_threads_equals_one_call(gpu):
         np.testing.assert_array_equal(np.concatenate([r[k] for r in parts]), whole[k])
 
 
+def test_streamed_curvefit_calls_from_three_threads_at_once(gpu, monkeypatch, capfd):
+    """Three host-array calls at the same time on one device, each as its own streamed persistent kernel (granules of 4 Ki
+    voxels so that the batches take that path): one works on the device's kept staging set, the others on private ones; a
+    kernel that cannot become resident while another occupies the registers starts when that one ends -- nobody waits for
+    anybody else's data, so the calls complete without running into the watermark poll limit, bit-equal to the single call."""
+    n = 250000 + 37  # each batch alone asks for more workgroups than the chip has CUs
+    b, y, p0, lo, hi = _triexp(n)
+    whole = gpu.curvefit("tri_reduced", b, y, p0, lo, hi)
+    monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "13")
+    monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "8192")
+    monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    cuts = [0, 80000, 165011, n]
+    capfd.readouterr()
+    with ThreadPoolExecutor(3) as ex:
+        parts = list(ex.map(lambda k: gpu.curvefit("tri_reduced", b, y[cuts[k]:cuts[k + 1]], p0, lo, hi), range(3)))
+    err = capfd.readouterr().err
+    assert err.count("granules of") == 3 and "TIMED OUT" not in err and "timed out" not in err
+    np.testing.assert_array_equal(np.concatenate([r["popt"] for r in parts], axis=1), whole["popt"])
+    np.testing.assert_array_equal(np.concatenate([r["pcov"] for r in parts], axis=0), whole["pcov"])
+    for k in ("status", "nfev", "cost"):
+        np.testing.assert_array_equal(np.concatenate([r[k] for r in parts]), whole[k])
+
+
 def test_nnls_abi_from_four_threads_equals_one_call(gpu):
     from pyneapple_amd import synth
 
