@@ -649,6 +649,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     sl.phase = 1;
     rc = curvefit_device(o, (int64_t)nv, bd, dy, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, dpopt, dpcov, dstat,
                          dnfev, dcost, dev, s_main, &sl);
+    if (rc == PNX_ERR_UNSUPPORTED) return kStreamRetry;  // no streamed instantiation for this combination: the ring has one
     if (rc) return rc;
     const double t_launched = now();
 
@@ -881,8 +882,11 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         const int gshift = env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
         const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2 + (fpv ? o->n_fixed : 0) + (pv ? 3 * n : 0)) * (F32 ? 12 : 8);
         const size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
-        if (env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && nv > ((size_t)1 << gshift) && nv < ((size_t)1 << 31) &&
-            nv * per_vox <= max_bytes) {
+        // not for the kernels that need (almost) every register of a lane (pnx_curvefit_inst.hip launch_pv): the copies that
+        // feed a streamed kernel have to fit beside it
+        const bool tight = n >= 6 || (n >= 4 && o->t1_mode);
+        if (env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
+            nv < ((size_t)1 << 31) && nv * per_vox <= max_bytes) {
             rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, pv ? p0 : nullptr, pv ? lo : nullptr, pv ? hi : nullptr, fxd,
                                       fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream);
             if (rc != kStreamRetry) return rc;

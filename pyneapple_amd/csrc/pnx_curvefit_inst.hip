@@ -64,11 +64,20 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
 template <int MODEL, int N, bool FD, bool T1> static int launch_pv(const CurvefitArgs &args, int cus, hipStream_t st) {
     if (args.ctl && args.phase != 2) {
         // streamed launch (host-array calls): shared p0 / bounds with any set of fixed parameters, per-voxel p0 / bounds with
-        // every parameter free (the combination of both stays with the chunk ring: it would double the build once more)
+        // every parameter free (the combination of both stays with the chunk ring: it would double the build once more).
+        // Not for the instantiations that need (almost) all 512 registers of a lane -- six or seven free parameters, or four
+        // and more with the T1 factor: 402-512 -- because the runtime's copy kernels, the conversions and the epilogue must
+        // become resident beside the fit.  (Leaving CUs free does not help below one per shader engine: with 8 of 256 CUs
+        // free the upload still sat behind the kernel until its poll limit, with 64 it ran; profiles/stream_tight_probe.py.)
         constexpr int NP = Model<MODEL>::NALL + (T1 ? 1 : 0);
-        if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
-        if constexpr (N == NP) return launch_one<MODEL, N, FD, true, T1, true>(args, cus, st);
-        return set_error(PNX_ERR_UNSUPPORTED, "streamed launch: per-voxel p0 / bounds together with fixed parameters");
+        constexpr bool kTight = (N >= 6) || (N >= 4 && T1);
+        if constexpr (kTight) {
+            return set_error(PNX_ERR_UNSUPPORTED, "streamed launch: %d free parameters%s leave no registers for the copies", N, T1 ? " + T1" : "");
+        } else {
+            if (!args.per_voxel) return launch_one<MODEL, N, FD, false, T1, true>(args, cus, st);
+            if constexpr (N == NP) return launch_one<MODEL, N, FD, true, T1, true>(args, cus, st);
+            return set_error(PNX_ERR_UNSUPPORTED, "streamed launch: per-voxel p0 / bounds together with fixed parameters");
+        }
     }
     return args.per_voxel ? launch_one<MODEL, N, FD, true, T1>(args, cus, st) : launch_one<MODEL, N, FD, false, T1>(args, cus, st);
 }

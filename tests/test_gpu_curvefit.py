@@ -392,6 +392,65 @@ def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, capfd, mo
         np.testing.assert_array_equal(cost.cpu().numpy(), ring["cost"])
 
 
+def test_streamed_host_path_with_the_t1_factor(gpu, monkeypatch, capfd):
+    """mono + T1 (three free parameters, STEAM factor): a streamed instantiation with the relaxation factor in the kernel
+    arguments; bi_reduced + T1 has four free parameters and is register tight (stays with the ring).  Same bits either way."""
+    from pyneapple_amd import synth
+
+    tr, tm = 3000.0, 25.0
+    for model, n_b, streamed in (("mono", 16, True), ("bi_reduced", 24, False)):
+        n_vox = 20000 + 5
+        b, y, _ = synth.make_numpy(model, n_vox, n_b, sigma=0.01, seed=19)
+        _, p0, lo, hi = synth.shared_arrays(model)
+        T1 = np.random.default_rng(4).uniform(800, 1600, n_vox)
+        y = y * ((1 - np.exp(-tr / T1)) * np.exp(-tm / T1))[:, None]
+        p0, lo, hi = np.append(p0, 1000.0), np.append(lo, 100.0), np.append(hi, 5000.0)
+        kw = dict(t1_mode=2, tr=tr, tm=tm, jac="analytic")
+        monkeypatch.setenv("PNX_HOST_STREAM", "0")
+        monkeypatch.delenv("PNX_HOST_TRACE", raising=False)
+        ring = gpu.curvefit(model, b, y, p0, lo, hi, **kw)
+        monkeypatch.setenv("PNX_HOST_STREAM", "1")
+        monkeypatch.setenv("PNX_HOST_TRACE", "1")
+        monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "11")
+        monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "3000")
+        capfd.readouterr()
+        st = gpu.curvefit(model, b, y, p0, lo, hi, **kw)
+        err = capfd.readouterr().err
+        assert ("[pnx stream]" in err) == streamed and "timed out" not in err
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            np.testing.assert_array_equal(st[k], ring[k], err_msg=f"{model} {k}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_register_tight_kernels_keep_the_chunk_ring(gpu, monkeypatch, capfd, dtype):
+    """Six free parameters (tri_full): the fit kernel needs all 512 registers of a lane, so neither the runtime's copy kernels
+    nor the covariance epilogue could become resident beside a streamed launch of it (measured: the upload sat behind the
+    kernel until its poll limit).  Such calls go through the chunk ring straight away -- no streamed attempt, no time-out."""
+    import time
+
+    from pyneapple_amd import synth
+
+    n_vox = 150000 + 7  # more workgroups than CUs, above the streaming threshold
+    b, y, _ = synth.make_numpy("tri_reduced", n_vox, 32, sigma=0.01, seed=21)
+    y = (y * 1000.0).astype(dtype)
+    p0 = np.array([200.0, 0.05, 300.0, 0.005, 500.0, 0.001])
+    lo = np.array([0.0, 0.01, 0.0, 2e-3, 0.0, 1e-5])
+    hi = np.array([2000.0, 0.5, 2000.0, 0.01, 2000.0, 2e-3])
+    monkeypatch.setenv("PNX_HOST_STREAM", "0")
+    ring = gpu.curvefit("tri_full", b, y, p0, lo, hi)
+    monkeypatch.setenv("PNX_HOST_STREAM", "1")
+    monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    capfd.readouterr()
+    t = time.perf_counter()
+    st = gpu.curvefit("tri_full", b, y, p0, lo, hi)
+    dt = time.perf_counter() - t
+    err = capfd.readouterr().err
+    assert "[pnx stream]" not in err and dt < 1.0
+    for k in ("popt", "pcov", "status", "nfev", "cost"):
+        np.testing.assert_array_equal(st[k], ring[k], err_msg=k)
+    assert (ring["status"] > 0).mean() > 0.98
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_streamed_host_path_with_fixed_parameters(gpu, monkeypatch, capfd, dtype):
     """Shared p0 / bounds with fixed parameters (analytic Jacobian) also run as one streamed kernel: a shared fixed value, and
