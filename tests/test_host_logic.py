@@ -219,3 +219,25 @@ def test_solver_n_gpus_sharding_reassembles_rows(monkeypatch):
     hi = np.tile(np.array([1.0, 0.1, 5e-3])[:, None], (1, n_vox))
     s.fit(b, y, p0=p0, bounds=(lo, hi))
     assert all(c[2] == (3, c[1]) for c in calls) and len(calls) == 4
+
+
+def test_result_arrays_handed_in_by_the_caller_are_checked():
+    """`out=` of api.curvefit / NnlsPlan.solve (row ranges of a larger array that several device shards fill): the right shape,
+    dtype and contiguity, or a ValueError -- never a silent copy."""
+    import numpy as np
+    import pytest
+
+    from pyneapple_amd import api
+
+    big = np.empty((10, 3, 3))
+    view = big[2:7]
+    assert api._out({"pcov": view}, "pcov", (5, 3, 3), np.float64) is view
+    fresh = api._out(None, "pcov", (5, 3, 3), np.float64)
+    assert fresh.shape == (5, 3, 3) and fresh.dtype == np.float64
+    assert api._out({"status": None}, "status", (4,), np.int8).shape == (4,)
+    with pytest.raises(ValueError):
+        api._out({"pcov": big[::2]}, "pcov", (5, 3, 3), np.float64)           # not contiguous
+    with pytest.raises(ValueError):
+        api._out({"pcov": view.astype(np.float32)}, "pcov", (5, 3, 3), np.float64)  # wrong dtype
+    with pytest.raises(ValueError):
+        api._out({"pcov": big[:4]}, "pcov", (5, 3, 3), np.float64)            # wrong shape
