@@ -229,7 +229,7 @@ def test_result_arrays_handed_in_by_the_caller_are_checked():
 
     from pyneapple_amd import api
 
-    big = np.empty((10, 3, 3))
+    big = np.zeros((10, 3, 3))
     view = big[2:7]
     assert api._out({"pcov": view}, "pcov", (5, 3, 3), np.float64) is view
     fresh = api._out(None, "pcov", (5, 3, 3), np.float64)
