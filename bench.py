@@ -635,8 +635,13 @@ def main(argv=None):
         tf = fl["fp64_flop_per_voxel_issued"] * leg.n_vox / k_avg / 1e12
         out["roofline"]["valu_f64"] = {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                                        "fp64_flop_per_voxel_issued": fl["fp64_flop_per_voxel_issued"],
-                                       "lane_utilisation": fl["lane_utilisation"], "source": fl["source"],
-                                       "source_id": fl["source_id"]}
+                                       "lane_utilisation": fl["lane_utilisation"],
+                                       # share of a SIMD's cycles in which the VALU issues (PMC pass: SQ_ACTIVE_INST_VALU /
+                                       # SQ_WAVE_CYCLES per wave, x resident waves per SIMD): the issue roof this kernel lives under
+                                       "valu_issue_busy_per_wave": fl.get("valu_issue_busy"), "waves_per_simd": 1,
+                                       "simd_valu_busy": min(1.0, fl.get("valu_issue_busy", 0.0) * 1),
+                                       "fp64_share_of_valu_instructions": fl.get("fp64_share_of_valu_instructions"),
+                                       "source": fl["source"], "source_id": fl["source_id"]}
     if args.workload != "nnls" and not args.no_pipelined:
         out["pipelined"] = leg.pipelined(max(args.steps, 4), world, dist)  # every rank takes part (barriers)
         # `value` is the strong-scaling figure north_star asks for: ONE volume, one pass at a time, so at N ranks it ends in the
@@ -674,8 +679,10 @@ def main(argv=None):
             sec["roofline"]["valu_f64"] = {"achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf2 / FP64_PEAK_TFLOPS,
                                            "fp64_flop_per_voxel_issued": fl2["fp64_flop_per_voxel_issued"],
                                            "fp64_share_of_valu_instructions": fl2["fp64_share_of_valu_instructions"],
-                                           "lane_utilisation": fl2["lane_utilisation"], "source": fl2["source"],
-                                           "source_id": fl2["source_id"]}
+                                           "lane_utilisation": fl2["lane_utilisation"],
+                                           "valu_issue_busy_per_wave": fl2.get("valu_issue_busy"), "waves_per_simd": 3,
+                                           "simd_valu_busy": min(1.0, fl2.get("valu_issue_busy", 0.0) * 3),
+                                           "source": fl2["source"], "source_id": fl2["source_id"]}
         if solo and not args.no_host_mode:
             sec["host_mode"] = leg2.host_mode()
         if solo and not args.no_cpu_baseline:

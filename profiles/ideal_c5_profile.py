@@ -23,3 +23,6 @@ pr.enable()
 fit.fit(b, img)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+import time
+t = time.perf_counter(); fit.fit(b, img); dt = time.perf_counter() - t
+print(f"third call {dt * 1e3:.1f} ms; per level (prepare, fit + statistics, map download) seconds: {fit.stage_times_}")
