@@ -59,3 +59,11 @@ def test_nnls_fuzz_100_cases(gpu, oracle):
     assert r["status_disagreements"] <= 0.002 * r["voxels"] + 2, r
     assert r["coefficient_disagreements"] <= 0.002 * r["voxels"] + 2, r
     assert r["rnorm_disagreements"] <= 2, r
+
+
+def test_streamed_host_path_fuzz_40_cases(gpu):
+    """Random configurations of the streamed host path against the chunk ring (tests/fuzz_stream_vs_ring.py): bit-identical
+    outputs, no watermark time-out, streamed exactly when the batch has two or more granules."""
+    r = _load("tests/fuzz_stream_vs_ring.py", "fuzz_stream").run(40, seed=20261004, verbose=True)
+    assert r["failing_cases"] == 0, r
+    assert r["streamed_cases"] >= 30
