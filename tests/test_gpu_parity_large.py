@@ -67,3 +67,11 @@ def test_streamed_host_path_fuzz_40_cases(gpu):
     r = _load("tests/fuzz_stream_vs_ring.py", "fuzz_stream").run(40, seed=20261004, verbose=True)
     assert r["failing_cases"] == 0, r
     assert r["streamed_cases"] >= 30
+
+
+def test_nnls_host_chunkings_fuzz_12_cases(gpu):
+    """Random chunkings of the NNLS host path (deferred / per-chunk / overflowing hand-over, float32, peak tables) against the
+    single-chunk call, on rows that contain handed-over voxels (tests/fuzz_nnls_host.py)."""
+    r = _load("tests/fuzz_nnls_host.py", "fuzz_nnls_host").run(12, seed=20261004, verbose=True)
+    assert r["failing_cases"] == 0, r
+    assert r["handed_over_voxels"] >= 1
