@@ -624,7 +624,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     }
     // pinned host: granule flags (written by the kernel), watermark values (source of the 8-byte copies), the abort word
     const size_t pin_bytes = sizeof(unsigned long long) * (size_t)(n_in + 1) + sizeof(unsigned int) * (size_t)n_gran;
-    if ((rc = res.ensure_pin(pin_bytes))) return rc;
+    if (res.ensure_pin(pin_bytes)) return kStreamRetry;  // no pinned memory to be had: the ring does without
     memset(res.pin, 0, pin_bytes);
     unsigned long long *wm = (unsigned long long *)res.pin;  // [n_in], then one word holding the abort value
     unsigned int *abort_src = (unsigned int *)(wm + n_in);
