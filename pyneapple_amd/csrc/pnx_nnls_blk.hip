@@ -55,6 +55,9 @@ constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
 // buffer of the M sweeps, and -- in the part of the dual that runs before the stencil -- holds xs[128] (x by position) and
 // rb[32] (residual of the measurements): every LDS byte not spent here keeps a row of M on the chip
 constexpr int kScr = kMaxPos / 2 + kXbuf;
+#ifndef PNX_BLK_ROT
+#define PNX_BLK_ROT 1
+#endif
 #ifndef PNX_BLK_LDS_ROWS
 #define PNX_BLK_LDS_ROWS 32
 #endif
@@ -213,6 +216,27 @@ template <int NI> __device__ __forceinline__ double reduce_scatter_a(const doubl
     return keep + dppx<0x128>(send);
 }
 
+// lanes <= k as a wave mask in scalar registers (k wave uniform): row masks cost no VALU compare
+__device__ __forceinline__ unsigned long long lanes_le(int k) {
+    return k >= 63 ? ~0ull : (k < 0 ? 0ull : ((2ull << k) - 1ull));
+}
+// position i receives the value of position i + 1, on DPP (wave_shl:1: lane l reads lane l + 1; lane 63 keeps `old` = lane 0 of
+// the next slot): two v_mov_dpp per double instead of two ds_bpermute round trips
+__device__ __forceinline__ double wshl1(double v, double last) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(last), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(last), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int NS> __device__ __forceinline__ void shift_down_dpp(const double (&a)[NS], double (&out)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[s] = wshl1(a[s], s + 1 < NS ? rl(a[s + 1 < NS ? s + 1 : s], 0) : 0.0);
+}
+template <int NS> __device__ __forceinline__ void shift_down_dpp_i(const int (&a)[NS], int (&out)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        out[s] = __builtin_amdgcn_update_dpp(s + 1 < NS ? __builtin_amdgcn_readlane(a[s + 1 < NS ? s + 1 : s], 0) : 0, a[s], 0x130, 0xf, 0xf, false);
+}
+
 // ---- products with the LDS-resident basis ------------------------------------------------------------------
 // stage x / pidx by position (zeros behind position p up to the end of its slot)
 __device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kPS],
@@ -311,8 +335,10 @@ __device__ __forceinline__ void bt_times(const double *Bl, const double *v, int 
 
 #ifdef PNX_NNLS_STAMP
 #define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
+#define COUNT(k, v) do { cnt[k] += (v); } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define COUNT(k, v) do {} while (0)
 #endif
 
 // The queue pull sits in a function of its own: inlined, its one-lane branch is merged by the compiler into the control flow
@@ -572,8 +598,9 @@ constexpr int kBail = 2;  // internal status: the passive set wants more than kM
 
 __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) {  // read through kargs()
 #ifdef PNX_NNLS_STAMP
-    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // voxels, outer iterations, rejected candidates, removals, rotated rows, sum of p at the dual, appends with p > 48, p > 64
 #endif
     extern __shared__ double dyn_lds[];
     const int lane = threadIdx.x & (kW - 1);
@@ -625,9 +652,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         int iteration = 0, status = finite ? 1 : -2;
         double w[kSlots];
         STAMP(0);
+        COUNT(0, 1);
 
         while (status == 1 && S.p < n && S.p < m_total) {
             // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
+            COUNT(1, 1);
+            COUNT(5, S.p);
+            COUNT(6, S.p > 48 ? 1 : 0);
+            COUNT(7, S.p > 64 ? 1 : 0);
             {
                 const int ld = fresh(lane);
                 lds_order();
@@ -636,8 +668,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                 const double bx = b_times_xp(Bl, xs, ps, S.p, ld);
                 if (ld < kBMeas) rb[ld] = yreg - bx;
                 lds_order();
+                STAMP(9);
                 bt_times(Bl, rb, ld, w);
                 lds_order();
+                STAMP(10);
                 double u[kSlots];
                 KArgs *K = kargs();
                 const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
@@ -682,6 +716,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                 else
                     accepted = try_append<6>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
                 if (accepted) break;
+                COUNT(2, 1);
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s)
@@ -746,6 +781,151 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     const int pp = __builtin_amdgcn_readfirstlane(S.p);
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
+#if PNX_BLK_ROT
+                    // Round 4: the rotation coefficients travel through LDS (one broadcast ds_read_b128 per row instead of
+                    // four v_readlane), q is rotated in closed form (the carried combination of q is a prefix sum:
+                    // carq_i = sum_{k = jj .. i} m_k q_k / a_i), row masks are scalar (no v_cmp), shifts are DPP moves;
+                    // batches of rows that lie wholly in LDS or wholly in the slab carry no per-row branch.
+                    double mv[kPS], pre[kPS], car[kPS];
+                    double carry = 0;
+                    wave_sync();
+                    int cofs[kPS];  // column read of the next row: column jj dropped
+                    {
+                        const int jbase = moff(jj);
+#pragma unroll
+                        for (int s = 0; s < kPS; ++s) {  // column jj (rows jj ..) and row jj (columns < jj): both reads in flight
+                            const int i = lane + kW * s;
+                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? (i < kLdsM ? M.l[i < kLdsM ? moff(i) + jj : 0] : M.g[CK(moff(i) + jj, kMSlab, 9, i)]) : 0.0;
+                            car[s] = (i < jj) ? M.ld(jj, jbase + i) : 0.0;
+                            cofs[s] = i < jj ? i : i + 1;
+                        }
+                    }
+                    double tq[kPS];  // prefix sums of m_k q_k
+                    {
+                        double carry2 = 0;
+#pragma unroll
+                        for (int s = 0; s < kPS; ++s) {
+                            pre[s] = carry;
+                            tq[s] = carry2;
+                            if (kW * s < pp) {
+                                const double sc = wave_incl_scan(mv[s] * mv[s]);
+                                pre[s] = sc + carry;
+                                carry += rl(sc, 63);
+                                const double sq = wave_incl_scan(mv[s] * S.q[s]);
+                                tq[s] = sq + carry2;
+                                carry2 += rl(sq, 63);
+                            }
+                        }
+                    }
+                    double mnext[kPS], prenext[kPS], qsh[kPS];
+                    shift_down_dpp(mv, mnext);
+                    shift_down_dpp(pre, prenext);
+                    shift_down_dpp(S.q, qsh);  // qsh[i] = q[i + 1]
+                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
+                                                : __builtin_amdgcn_readlane(S.pidx[1], jj & 63);
+                    double2 *cf = reinterpret_cast<double2 *>(xbuf);  // (c_i, s_i) by position: xbuf is free during a removal
+                    lds_order();
+#pragma unroll
+                    for (int s = 0; s < kPS; ++s) {
+                        const int i = lane + kW * s;
+                        if (kW * s < pp) {  // wave uniform
+                            double c_ = 1.0, s_ = 0.0;
+                            if (i >= jj && i < pp - 1) {
+                                // a = sqrt(pre) (the first carried value keeps its sign), r = sqrt(prenext): c = m_next / r, s = a / r
+                                const double ir = prenext[s] > 0 ? rsqrt_nr(prenext[s]) : 0.0;
+                                const double ip = pre[s] > 0 ? rsqrt_nr(pre[s]) : 0.0;
+                                const double a = (i == jj) ? mv[s] : pre[s] * ip;
+                                if (prenext[s] > 0) {
+                                    c_ = mnext[s] * ir;
+                                    s_ = a * ir;
+                                }
+                                const double cq = (i == jj) ? S.q[s] : tq[s] * ip;
+                                S.q[s] = c_ * cq - s_ * qsh[s];
+                            }
+                            cf[i] = double2{c_, s_};
+                        }
+                    }
+                    lds_order();
+                    STAMP(11);
+                    COUNT(3, 1);
+                    COUNT(4, pp - 1 - jj);
+                    {
+                        // row i of the new factor from the carried combination and old row i + 1 (column jj dropped); the
+                        // loads of a batch of rows and their coefficients are in flight before its first rotation
+                        auto rows = [&](int i, auto T, auto NB, auto RG) {
+                            constexpr int si = decltype(T)::value;
+                            constexpr int nb = decltype(NB)::value;
+                            constexpr int rg = decltype(RG)::value;  // 0: rows i .. i + nb in LDS, 1: all in the slab, 2: decided per row
+                            double nx[nb][si + 1];
+                            double2 c2[nb];
+#pragma unroll
+                            for (int r = 0; r < nb; ++r) {
+                                const int nbase = moff(i + r + 1);
+#pragma unroll
+                                for (int s = 0; s <= si; ++s) {
+                                    const int idx = nbase + cofs[s];
+                                    nx[r][s] = rg == 0 ? M.l[idx] : (rg == 1 ? M.g[CK(idx, kMSlab, 10, i + r)] : M.ld(i + r + 1, idx));
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < nb; ++r) c2[r] = cf[i + r];
+#pragma unroll
+                            for (int r = 0; r < nb; ++r) {
+                                const double c_ = c2[r].x, s_ = c2[r].y;
+                                const int obase = moff(i + r);
+#pragma unroll
+                                for (int s = 0; s <= si; ++s) {
+                                    if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(i + r - kW * s))) {
+                                        const double outv = c_ * car[s] - s_ * nx[r][s];
+                                        car[s] = s_ * car[s] + c_ * nx[r][s];
+                                        const int oidx = obase + lane + kW * s;
+                                        if (rg == 0)
+                                            M.l[oidx] = outv;
+                                        else if (rg == 1)
+                                            M.g[CK(oidx, kMSlab, 11, i + r)] = outv;
+                                        else
+                                            M.st(i + r, oidx, outv);
+                                    }
+                                }
+                            }
+                        };
+                        const int hi = pp - 1;
+                        const int e = hi < kW ? hi : kW;
+                        int i = jj;
+                        while (i < e) {  // rows < 64: one register slot
+                            const int left = e - i;
+                            if (i >= kLdsM) {
+                                if (left >= 8) {
+                                    rows(i, SlotTag<0>{}, SlotTag<8>{}, SlotTag<1>{});
+                                    i += 8;
+                                } else if (left >= 4) {
+                                    rows(i, SlotTag<0>{}, SlotTag<4>{}, SlotTag<1>{});
+                                    i += 4;
+                                } else {
+                                    rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<1>{});
+                                    i += 1;
+                                }
+                            } else if (left >= 8 && i + 8 < kLdsM) {
+                                rows(i, SlotTag<0>{}, SlotTag<8>{}, SlotTag<0>{});
+                                i += 8;
+                            } else if (left >= 4 && i + 4 < kLdsM) {
+                                rows(i, SlotTag<0>{}, SlotTag<4>{}, SlotTag<0>{});
+                                i += 4;
+                            } else if (i + 1 < kLdsM) {
+                                rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<0>{});
+                                i += 1;
+                            } else {
+                                rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<2>{});
+                                i += 1;
+                            }
+                        }
+                        if (hi > kW) {
+                            i = jj > kW ? jj : kW;
+                            for (; i + 4 <= hi; i += 4) rows(i, SlotTag<1>{}, SlotTag<4>{}, SlotTag<1>{});
+                            for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{}, SlotTag<1>{});
+                        }
+                    }
+#else
                     double mv[kPS], pre[kPS], car[kPS];
                     double carry = 0;
                     wave_sync();
@@ -838,6 +1018,9 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             }
                         };
                         const int hi = pp - 1;
+                        STAMP(11);
+                        COUNT(3, 1);
+                        COUNT(4, hi - jj);
 #pragma unroll
                         for (int r = 0; r < kFirst; ++r) {  // the prefetched rows
                             if (r >= nfirst) break;
@@ -869,12 +1052,18 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{});
                         }
                     }
+#endif
                     // ---- drop position jj from x / pidx
                     {
                         double xsh[kPS];
                         int psh[kPS];
+#if PNX_BLK_ROT
+                        shift_down_dpp(S.x, xsh);
+                        shift_down_dpp_i(S.pidx, psh);
+#else
                         shift_down(S.x, xsh, lane);
                         shift_down_i(S.pidx, psh, lane);
+#endif
 #pragma unroll
                         for (int s = 0; s < kPS; ++s) {
                             const int i = lane + kW * s;
@@ -973,7 +1162,9 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     }
 #ifdef PNX_NNLS_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 7)
-        printf("STAMP setup=%llu dual=%llu cand+append=%llu sync=%llu alpha=%llu removal=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6], seg[7], seg[8]);
+        printf("STAMP setup=%llu dual_bx=%llu dual_bt=%llu dual_reg=%llu cand+append=%llu sync=%llu alpha=%llu removal_head=%llu removal_rows=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[9], seg[10], seg[1], seg[2], seg[3], seg[4], seg[11], seg[5], seg[6], seg[7], seg[8]);
+    if (threadIdx.x == 0 && blockIdx.x == 7)
+        printf("COUNT voxels=%lld outer=%lld rejects=%lld removals=%lld rot_rows=%lld sum_p=%lld p_gt48=%lld p_gt64=%lld\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]);
 #endif
 }
 
