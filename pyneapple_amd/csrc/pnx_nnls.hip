@@ -834,7 +834,7 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
                                  "%.3g); use a regulariser or at most 64 measurements", n_meas, pmin, gmax);
         }
     }
-    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)kNnlsMaxBins * kNnlsMaxBins;
+    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)(kNnlsMaxBins + 1) * kNnlsMaxBins;  // one row more: the block kernel gathers column 256 (its padding bin) of a row
     for (size_t i = 0; i < nb; ++i)
         if (!std::isfinite(basis[i])) return set_error(PNX_ERR_INVALID, "basis contains non-finite values");
     PNX_HIPN(hipMalloc(&P->B, nb * sizeof(double)));

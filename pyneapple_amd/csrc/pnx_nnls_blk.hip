@@ -54,7 +54,12 @@ constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
 // per-wave LDS scratch, in doubles: ps[128] (ints) bin by position | xbuf[264] x by bin with halo.  xbuf is also the staging
 // buffer of the M sweeps, and -- in the part of the dual that runs before the stencil -- holds xs[128] (x by position) and
 // rb[32] (residual of the measurements): every LDS byte not spent here keeps a row of M on the chip
-constexpr int kScr = kMaxPos / 2 + kXbuf;
+#ifndef PNX_BLK_DUAL2
+#define PNX_BLK_DUAL2 1  // round 4: x is gathered by bin out of xbuf, the residual of the measurements has a place of its own, the two
+                         // stencil passes ride on the round trips of the column gathers and of the B^T r product
+#endif
+constexpr int kPadBin = kNnlsMaxBins;  // bin of the padding positions: column 256 of the LDS basis and xbuf[2 + 256] are zero
+constexpr int kScr = kMaxPos / 2 + kXbuf + (PNX_BLK_DUAL2 ? 32 : 0);
 #ifndef PNX_BLK_ROT
 #define PNX_BLK_ROT 1
 #endif
@@ -367,13 +372,202 @@ __device__ __forceinline__ KArgs *kargs() {
     return p;
 }
 
+// owner of a bin: binof(lane, slot) = 128 (slot >> 1) + 2 lane + (slot & 1)
+__device__ __forceinline__ int slot_of_bin(int j) { return ((j >> 7) << 1) | (j & 1); }
+__device__ __forceinline__ int lane_of_bin(int j) { return (j >> 1) & 63; }
 // per-voxel state that the phases below share
 struct VoxState {
     double q[kPS], x[kPS], z[kPS];  // by position
     int pidx[kPS];                  // bin of a position
-    bool inP[kSlots];               // by bin
+    unsigned long long inP[kSlots];  // by bin, as wave masks in scalar registers (bit l of inP[s]: bin binof(l, s)); bins >= n_bins count as taken
     int p;
 };
+
+// ---- round 4: the dual with its LDS round trips overlapped ---------------------------------------------------
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ unsigned lds_addr(const double *q) { return (unsigned)(size_t)q; }  // the LDS byte address is the low half of the flat one
+__device__ __forceinline__ double lds_at(unsigned a) { return *reinterpret_cast<lds_cdouble *>((size_t)a); }
+// x by bin into xbuf (halo zeroed) and the bins by position into ps, padded with kPadBin to the end of the slot
+__device__ __forceinline__ void stage_bins(double *xbuf, lds_int *ps, int p, int lane, const double (&x)[kPS], const int (&pidx)[kPS]) {
+    const double2 zero2 = {0.0, 0.0};
+    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
+    *reinterpret_cast<double2 *>(lo) = zero2;
+    *reinterpret_cast<double2 *>(hi) = zero2;
+    if (lane < 2) *reinterpret_cast<double2 *>(xbuf + 258 * lane) = zero2;
+    lds_order();
+#pragma unroll
+    for (int s = 0; s < kPS; ++s) {
+        const int i = lane + kW * s;
+        if (kW * s <= p && i < kMaxPos) {  // wave uniform
+            ps[i] = (int)lds_addr(xbuf + 2) + 8 * (i < p ? pidx[s] : kPadBin);  // LDS address of x by bin: a gather of x needs no address arithmetic
+            if (i < p) xbuf[2 + pidx[s]] = x[s];
+        }
+    }
+    lds_order();
+}
+// the pair of bins at q and its two neighbours on either side: three 16-byte reads
+struct Win {
+    double2 lo, mid, hi;
+};
+__device__ __forceinline__ Win load_win(const double *q) {
+    Win w;
+    w.lo = *reinterpret_cast<const double2 *>(q - 2);
+    w.mid = *reinterpret_cast<const double2 *>(q);
+    w.hi = *reinterpret_cast<const double2 *>(q + 2);
+    return w;
+}
+// taps d = -2 .. 2 of out_j = sum_d c[d + 2] v[j + d]  (REV: c[2 - d], the transposed band)
+template <bool REV, int HB> __device__ __forceinline__ void band_eval(const Win &w, const double (&c)[5], double &o0, double &o1) {
+    const double cm1 = REV ? c[3] : c[1], cp1 = REV ? c[1] : c[3], cm2 = REV ? c[4] : c[0], cp2 = REV ? c[0] : c[4];
+    double a = cm1 * w.lo.y, b = cm1 * w.mid.x;
+    a = fma(c[2], w.mid.x, a);
+    b = fma(c[2], w.mid.y, b);
+    a = fma(cp1, w.mid.y, a);
+    b = fma(cp1, w.hi.x, b);
+    if (HB > 1) {
+        a = fma(cm2, w.lo.x, a);
+        b = fma(cm2, w.lo.y, b);
+        a = fma(cp2, w.hi.x, a);
+        b = fma(cp2, w.hi.y, b);
+    }
+    o0 = a;
+    o1 = b;
+}
+template <bool REV> __device__ __forceinline__ void band_eval4(int hb, const Win &wl, const Win &wh, const double (&c)[5], double (&o)[kSlots]) {
+    if (hb > 1) {
+        band_eval<REV, 2>(wl, c, o[0], o[1]);
+        band_eval<REV, 2>(wh, c, o[2], o[3]);
+    } else {
+        band_eval<REV, 1>(wl, c, o[0], o[1]);
+        band_eval<REV, 1>(wh, c, o[2], o[3]);
+    }
+}
+// every lane: (B_P x_P)[m], m = lane & 31, with x read by bin out of xbuf.  Half wave h takes the positions 16 k + 8 h ..
+// + 7 of step k (two ds_read_b128 bring their bins); the bins of step k + 1 are requested before the gathers of step k, so
+// a step costs one LDS round trip.  `between` runs while the gathers of the first step are in flight.
+template <class F>
+__device__ __forceinline__ double bx_gather(const double *Bl, const double *xbuf, const lds_int *ps, int p, int lane, F &&between) {
+    const int m = lane & 31, h = lane >> 5;
+    const unsigned cB = lds_addr(Bl + m * kBStride) - lds_addr(xbuf + 2);  // from x of a bin to this lane's element of the bin's column
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    const lds_int *pj = ps + 8 * h;
+    int4v j0 = *reinterpret_cast<const int4v *>(pj), j1 = *reinterpret_cast<const int4v *>(pj + 4);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    double bv[8], xv[8];
+    auto issue = [&](int i) {
+        const unsigned jv[8] = {(unsigned)j0.x, (unsigned)j0.y, (unsigned)j0.z, (unsigned)j0.w, (unsigned)j1.x, (unsigned)j1.y, (unsigned)j1.z, (unsigned)j1.w};
+        j0 = *reinterpret_cast<const int4v *>(pj + i + 16);  // beyond the staged part: stale entries, never used
+        j1 = *reinterpret_cast<const int4v *>(pj + i + 20);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bv[u] = lds_at(jv[u] + cB);
+            xv[u] = lds_at(jv[u]);
+        }
+    };
+    auto consume = [&]() {
+        a0 = fma(xv[0], bv[0], a0);
+        a1 = fma(xv[1], bv[1], a1);
+        a2 = fma(xv[2], bv[2], a2);
+        a3 = fma(xv[3], bv[3], a3);
+        a0 = fma(xv[4], bv[4], a0);
+        a1 = fma(xv[5], bv[5], a1);
+        a2 = fma(xv[6], bv[6], a2);
+        a3 = fma(xv[7], bv[7], a3);
+    };
+    issue(0);  // p = 0: padding positions only (zeros)
+    between();
+    consume();
+    for (int i = 16; i < p; i += 16) {
+        issue(i);
+        consume();
+    }
+    return swap_add32((a0 + a1) + (a2 + a3));
+}
+// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m] as bt_times; `between` runs behind the first eight row reads
+template <class F>
+__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int lane, double (&out)[kSlots], F &&between) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) out[s] = 0;
+    const double *col = Bl + 2 * lane;
+    double2 c0[4], c1[4], d0[4], d1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
+        c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
+    }
+    between();
+#pragma unroll 1
+    for (int m = 0; m < kBMeas; m += 8) {
+        const double *nx = col + (m + 4) * kBStride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
+            d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
+        }
+        {
+            const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
+            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
+            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[0] = fma(c0[r].x, vv[r], out[0]);
+                out[1] = fma(c0[r].y, vv[r], out[1]);
+                out[2] = fma(c1[r].x, vv[r], out[2]);
+                out[3] = fma(c1[r].y, vv[r], out[3]);
+            }
+        }
+        const double *ny = col + ((m + 8) & (kBMeas - 1)) * kBStride;  // the last step re-reads rows 0 .. 3 (unused)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c0[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride);
+            c1[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride + 128);
+        }
+        {
+            const double2 v01 = *reinterpret_cast<const double2 *>(v + m + 4);
+            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 6);
+            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                out[0] = fma(d0[r].x, vv[r], out[0]);
+                out[1] = fma(d0[r].y, vv[r], out[1]);
+                out[2] = fma(d1[r].x, vv[r], out[2]);
+                out[3] = fma(d1[r].y, vv[r], out[3]);
+            }
+        }
+    }
+}
+// w = B^T (y - B_P x_P) - R^T (R x), all out of LDS.  LDS round trips in sequence: bins of the first positions -> column
+// gathers (one per 16 positions) -> B^T r; the stencil of R rides on the first gathers, the one of R^T on the first row reads.
+__device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbuf, lds_int *ps, double *rb, const double (&rc)[5], int hb,
+                                                   int n, int lane, double yreg, const VoxState &S, double (&w)[kSlots]) {
+    const int p = __builtin_amdgcn_readfirstlane(S.p);
+    lds_order();
+    stage_bins(xbuf, ps, p, lane, S.x, S.pidx);
+    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
+    const Win wl = load_win(lo), wh = load_win(hi);
+    double t[kSlots];
+    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() {
+        band_eval4<false>(hb, wl, wh, rc, t);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) t[s] = (binof(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
+    });
+    lds_order();
+    if (lane < kBMeas) rb[lane] = yreg - bx;
+    // t by bin through xbuf: every gather of x has been issued, and the LDS executes a wave's instructions in order
+    *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
+    *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
+    lds_order();
+    const Win ul = load_win(lo), uh = load_win(hi);
+    lds_order();
+    double u[kSlots];
+    bt_times_h(Bl, rb, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); });  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    lds_order();
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        w[s] -= u[s];
+        if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s])) w[s] = -INFINITY;
+    }
+}
 
 // blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
 // The block rows of M that live in the global slab (8 I >= kLdsM), K <= I < NI: every load is issued before the first use.
@@ -405,6 +599,9 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
                                            double wj, VoxState &S) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const double *grow = G + (size_t)jmax * kNnlsMaxBins;
+#if PNX_BLK_DUAL2
+    const int ps_base = (int)lds_addr(reinterpret_cast<const double *>(ps) + kMaxPos / 2 + 2);  // = xbuf + 2 of this wave
+#endif
     double blk[NI][NI];
     wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
     load_blocks<NI>(M, la, lb, blk);
@@ -414,7 +611,11 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #pragma unroll
     for (int K = 0; K < NI; ++K) {  // no mask: behind position p the staged bins are 0 and the columns of M are zero
         const int k = 8 * K + lb;
+#if PNX_BLK_DUAL2
+        gc[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + (unsigned)(ps[k] - ps_base));  // ps holds LDS addresses of x by bin
+#else
         gc[K] = grow[CK(ps[k], kNnlsMaxBins, 3, k)];
+#endif
     }
     double rK[NI];  // column sums of l^T M, lane (a, b) holds the partial sum over its rows of column 8 K + b
 #pragma unroll
@@ -491,8 +692,13 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     const double ilam = indep ? rsqrt_nr(lam2) : 0.0;
     double lam = lam2 * ilam;
     lam = fma(0.5 * ilam, fma(-lam, lam, lam2), lam);  // sqrt(lam2) to within an ulp
-    const double un = ll > 0 ? ll * rsqrt_nr(ll) : 0.0;
-    bool ok = ((un + lam * 0.01) - un) > 0;  // Lawson-Hanson linear-independence test
+    // Lawson-Hanson linear-independence test: (|l| + 0.01 lam) - |l| > 0.  It can only fail where 0.01 lam is below half an
+    // ulp of |l|, i.e. lam^2 < ~1e-28 |l|^2: |l| = sqrt(ll) is computed on that side of a generous threshold only
+    bool ok = true;
+    if (!(lam2 > 1e-24 * ll)) {
+        const double un = ll > 0 ? ll * rsqrt_nr(ll) : 0.0;
+        ok = ((un + lam * 0.01) - un) > 0;
+    }
     // ztest = qn / lam with qn = (a_j^T residual) / lam: the residual-form dual w_j IS a_j^T residual
     const double qn = wj * ilam;
     ok = ok && qn > 0;
@@ -524,7 +730,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
-        if (binof(lane, s) == jmax) S.inP[s] = true;
+        S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;  // scalar: jmax is wave uniform
     put(S.q, p, qn, lane);
     put(S.x, p, 0.0, lane);
     put_i(S.pidx, p, jmax, lane);
@@ -613,8 +819,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     double *Bl = dyn_lds + kBlkWaves * kScr;
     lds_int *ps = reinterpret_cast<lds_int *>(scr);                    // [128] bin by position
     double *xbuf = scr + kMaxPos / 2;                                  // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
+#if PNX_BLK_DUAL2
+    double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
+#else
     double *xs = xbuf;                                                 // [128] x by position: dead before the stencil fills xbuf
     double *rb = xbuf + kMaxPos;                                       // [32] residual of the measurements: likewise
+#endif
     MRef M;
     M.g = kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
     M.l = dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles;
@@ -647,7 +857,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             S.pidx[s] = 0;
         }
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) S.inP[s] = false;
+        for (int s = 0; s < kSlots; ++s) S.inP[s] = __ballot(binof(lane, s) >= n);
         S.p = 0;
         int iteration = 0, status = finite ? 1 : -2;
         double w[kSlots];
@@ -660,6 +870,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             COUNT(5, S.p);
             COUNT(6, S.p > 48 ? 1 : 0);
             COUNT(7, S.p > 64 ? 1 : 0);
+#if PNX_BLK_DUAL2
+            {
+                const int ld = fresh(lane);
+                KArgs *K = kargs();
+                const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
+                dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, ld, yreg, S, w);
+            }
+#else
             {
                 const int ld = fresh(lane);
                 lds_order();
@@ -679,9 +897,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
                     w[s] -= u[s];
-                    if (S.inP[s] || binof(ld, s) >= n) w[s] = -INFINITY;
+                    if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s])) w[s] = -INFINITY;
                 }
             }
+#endif
             STAMP(1);
 
             bool accepted = false;
@@ -1074,7 +1293,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                         }
 #pragma unroll
                         for (int s = 0; s < kSlots; ++s)
-                            if (binof(lane, s) == bin_out) S.inP[s] = false;
+                            S.inP[s] &= ~((s == slot_of_bin(bin_out)) ? (1ull << lane_of_bin(bin_out)) : 0ull);
                     }
                     if (pp - 1 < kLdsM) {  // the vacated last row: LDS rows >= p of M stay zero (the block sweeps mask global rows only)
                         const int vbase = moff(pp - 1);
@@ -1115,15 +1334,34 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         // ---- the next voxel starts from an all-zero LDS part of M
         {
             const int pe = __builtin_amdgcn_readfirstlane(S.p) < kLdsM ? __builtin_amdgcn_readfirstlane(S.p) : kLdsM;
-            for (int i = 0; i < pe; ++i) {  // the LDS rows only (kLdsM <= 64: one register slot)
-                const int width = 8 * ((i >> 3) + 1);
-                if (lane < width) M.l[moff(i) + lane] = 0.0;
+            if (pe > 0) {  // the LDS rows only: the whole area in 16-byte stores (five per lane) instead of a store per row
+                const double2 zero2 = {0.0, 0.0};
+                for (int e = 2 * lane; e < kLdsMDoubles; e += 2 * kW) *reinterpret_cast<double2 *>(M.l + e) = zero2;
             }
         }
         // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
         double xb[kSlots] = {0, 0, 0, 0};
         double rn;
         if (status == 1) {
+#if PNX_BLK_DUAL2
+            double tt = 0;
+            KArgs *K = kargs();
+            const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
+            const int pf = __builtin_amdgcn_readfirstlane(S.p);
+            lds_order();
+            stage_bins(xbuf, ps, pf, lane, S.x, S.pidx);
+            const Win wl = load_win(xbuf + 2 + 2 * lane), wh = load_win(xbuf + 130 + 2 * lane);
+            double t[kSlots];
+            const double bx = bx_gather(Bl, xbuf, ps, pf, lane, [&]() { band_eval4<false>(K->rhb, wl, wh, rc, t); });
+            lds_order();
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if (binof(lane, s) < n) tt = fma(t[s], t[s], tt);  // rows >= n of R do not exist
+            xb[0] = wl.mid.x;
+            xb[1] = wl.mid.y;
+            xb[2] = wh.mid.x;
+            xb[3] = wh.mid.y;
+#else
             double tt = 0, dummy[kSlots];
             lds_order();
             KArgs *K = kargs();
@@ -1136,6 +1374,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             lds_order();
             const double bx = b_times_xp(Bl, xs, ps, S.p, lane);
             lds_order();
+#endif
             const double r = lane < kBMeas ? yreg - bx : 0.0;
             rn = sqrt(wave_sum(fma(r, r, tt)));
         } else
