@@ -118,14 +118,29 @@ static_assert(kLdsMDoubles == moff(kLdsM) && kLdsM % 8 == 0, "LDS part of M: who
 
 // M of one wave: rows < kLdsM in LDS, the others in the wave's global slab (same offsets moff(i) + k in both).  A row index
 // that is wave uniform picks its memory with a scalar branch.
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(1))) double glb_double;
 struct MRef {
-    double *l;  // LDS, kLdsMDoubles
-    double *g;  // global slab, kMSlab
-    __device__ __forceinline__ double ld(int row, int idx) const { return row < kLdsM ? l[idx] : g[CK(idx, kMSlab, 20, row)]; }
+    // typed by address space: a branch "LDS or slab" then cannot be folded into one flat access through a selected base
+    // pointer (a flat access waits for both the LDS and the vector-memory counter)
+    lds_double *l;  // LDS, kLdsMDoubles
+    glb_double *g;  // global slab, kMSlab
+    // The empty asm keeps the two branches apart: without it the compiler folds them into ONE flat access through a selected
+    // base pointer, and a flat access waits for both the LDS and the vector-memory counter.
+    __device__ __forceinline__ double ld(int row, int idx) const {
+        double v;
+        if (row < kLdsM) {
+            asm volatile("" ::: "memory");
+            v = l[idx];
+        } else
+            v = g[CK(idx, kMSlab, 20, row)];
+        return v;
+    }
     __device__ __forceinline__ void st(int row, int idx, double v) const {
-        if (row < kLdsM)
+        if (row < kLdsM) {
+            asm volatile("" ::: "memory");
             l[idx] = v;
-        else
+        } else
             g[CK(idx, kMSlab, 21, row)] = v;
     }
 };
@@ -594,14 +609,26 @@ template <int NI> __device__ __forceinline__ void block_row(const MRef &M, int I
 // Returns false when the column is rejected (nothing changed).
 // One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
 // the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
+#if PNX_BLK_DUAL2
+// What an append needs that does not depend on the candidate, requested before the arg-max so that its latency hides behind it:
+// the bins of the positions in column layout (as byte offsets into a row of G).  (The blocks of M that live in the slab would
+// qualify too, but held across the arg-max they push the append out of its registers: 64 -> 256 bytes of scratch, measured.)
+template <int NI>
+__device__ __forceinline__ void append_prefetch(const lds_int *ps, int lb, unsigned (&goff)[NI]) {
+    const int ps_base = (int)lds_addr(reinterpret_cast<const double *>(ps) + kMaxPos / 2 + 2);  // = xbuf + 2 of this wave
+#pragma unroll
+    for (int K = 0; K < NI; ++K) goff[K] = (unsigned)(ps[8 * K + lb] - ps_base);  // ps holds LDS addresses of x by bin
+}
+#endif
 template <int NI>
 __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const lds_int *ps, int lane, int la, int lb, int jmax,
-                                           double wj, VoxState &S) {
+                                           double wj, VoxState &S
+#if PNX_BLK_DUAL2
+                                           , const unsigned (&goff)[NI]
+#endif
+) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const double *grow = G + (size_t)jmax * kNnlsMaxBins;
-#if PNX_BLK_DUAL2
-    const int ps_base = (int)lds_addr(reinterpret_cast<const double *>(ps) + kMaxPos / 2 + 2);  // = xbuf + 2 of this wave
-#endif
     double blk[NI][NI];
     wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
     load_blocks<NI>(M, la, lb, blk);
@@ -610,10 +637,10 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     double gc[NI];
 #pragma unroll
     for (int K = 0; K < NI; ++K) {  // no mask: behind position p the staged bins are 0 and the columns of M are zero
-        const int k = 8 * K + lb;
 #if PNX_BLK_DUAL2
-        gc[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + (unsigned)(ps[k] - ps_base));  // ps holds LDS addresses of x by bin
+        gc[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + goff[K]);
 #else
+        const int k = 8 * K + lb;
         gc[K] = grow[CK(ps[k], kNnlsMaxBins, 3, k)];
 #endif
     }
@@ -738,6 +765,39 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     return true;
 }
 
+#if PNX_BLK_DUAL2
+// The candidate loop of an outer iteration: largest positive dual (ties: lowest bin), append, or zero the dual of a rejected
+// column and look again.  Returns false when no column entered (KKT satisfied).
+template <int NI>
+__device__ __forceinline__ bool candidate(const double *G, const MRef &M, const lds_int *ps, int lc, double (&w)[kSlots], VoxState &S) {
+    const int la = lc >> 3, lb = lc & 7;
+    unsigned goff[NI];
+    append_prefetch<NI>(ps, lb, goff);
+    for (;;) {
+        const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
+        if (!(best > 0)) return false;  // KKT satisfied
+        // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
+        int jmax;
+        {
+            const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
+            const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
+            const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
+            const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
+            const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
+            const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
+            const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
+            jmax = lo < hi ? lo : hi;
+        }
+        if (jmax == kNone) return false;  // cannot happen (some lane holds the maximum); never index G with it
+        if (try_append<NI>(G, M, ps, lc, la, lb, jmax, best, S, goff)) return true;
+        // reject: w[j] = 0 and look for the next largest
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s)
+            if (binof(lc, s) == jmax) w[s] = 0.0;
+    }
+}
+#endif
+
 // z = M^T q
 template <int NI>
 __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane, int la, int lb, VoxState &S) {
@@ -826,8 +886,8 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     double *rb = xbuf + kMaxPos;                                       // [32] residual of the measurements: likewise
 #endif
     MRef M;
-    M.g = kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab;
-    M.l = dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles;
+    M.g = (glb_double *)(kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab);
+    M.l = (lds_double *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles);
     for (int e = lane; e < kLdsMDoubles; e += kW) M.l[e] = 0.0;  // rows >= p of M are zero, from the first voxel on
     for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
         const int m = e / kBStride, j = e - m * kBStride;
@@ -903,6 +963,25 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #endif
             STAMP(1);
 
+#if PNX_BLK_DUAL2
+            bool accepted = false;
+            {
+                if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: hand the voxel over unless it is done
+                    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
+                    if (best > 0) status = kBail;
+                } else {
+                    const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
+                    const int lc = fresh(lane);
+                    const double *Gp = kargs()->G;
+                    if (nI <= 2)
+                        accepted = candidate<2>(Gp, M, ps, lc, w, S);
+                    else if (nI <= 4)
+                        accepted = candidate<4>(Gp, M, ps, lc, w, S);
+                    else
+                        accepted = candidate<6>(Gp, M, ps, lc, w, S);
+                }
+            }
+#else
             bool accepted = false;
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
@@ -941,6 +1020,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                 for (int s = 0; s < kSlots; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;
             }
+#endif
             STAMP(2);
             if (!accepted) break;
             STAMP(3);
@@ -953,46 +1033,40 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     break;
                 }
                 const int p = __builtin_amdgcn_readfirstlane(S.p);
-                {
-                    bool viol = false;
+                // positions with z <= 0 as wave masks (the range test i < p is scalar: no vector compare, and the second
+                // register slot is looked at only where it is in use)
+                unsigned long long vm[kPS];
+                vm[0] = __ballot(S.z[0] <= 0) & lanes_le(p - 1);
+                vm[1] = p > kW ? (__ballot(S.z[1] <= 0) & lanes_le(p - 1 - kW)) : 0ull;
+                if (!(vm[0] | vm[1])) {  // feasible: x = z (positions >= p hold nothing that is read)
 #pragma unroll
-                    for (int s = 0; s < kPS; ++s) viol = viol || (lane + kW * s < p && S.z[s] <= 0);
-                    if (!__any(viol ? 1 : 0)) {
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s)
-                            if (lane + kW * s < p) S.x[s] = S.z[s];
-                        break;
-                    }
-                }
-                double bestT = INFINITY;
-                int bpos = kNone;
-#pragma unroll
-                for (int s = 0; s < kPS; ++s) {
-                    const int i = lane + kW * s;
-                    if (i < p && S.z[s] <= 0) {
-                        const double T = -S.x[s] / (S.z[s] - S.x[s]);
-                        if (T < bestT) {
-                            bestT = T;
-                            bpos = i;
-                        }
-                    }
-                }
-                {
-                    const double gmin = wave_min(bestT);
-                    bpos = (bestT == gmin && bpos != kNone) ? bpos : kNone;
-                    bpos = wave_min_i(bpos);  // ties: first position (Lawson-Hanson keeps the first minimum)
-                    bestT = gmin;
-                }
-                if (bpos == kNone) {
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s)
-                        if (lane + kW * s < p) S.x[s] = S.z[s];
+                    for (int s = 0; s < kPS; ++s) S.x[s] = S.z[s];
                     break;
                 }
-                const double alpha = bestT;
+                double T[kPS];
 #pragma unroll
-                for (int s = 0; s < kPS; ++s)
-                    if (lane + kW * s < p) S.x[s] = S.x[s] + alpha * (S.z[s] - S.x[s]);
+                for (int s = 0; s < kPS; ++s) {
+                    T[s] = INFINITY;
+                    if (vm[s]) {  // wave uniform
+                        if (__builtin_amdgcn_inverse_ballot_w64(vm[s])) T[s] = -S.x[s] / (S.z[s] - S.x[s]);
+                    }
+                }
+                // smallest step (ties: first position -- Lawson-Hanson keeps the first minimum)
+                const double alpha = -uni(allreduce_max(-(T[1] < T[0] ? T[1] : T[0])));
+                int bpos;
+                {
+                    const unsigned long long b0 = __ballot(T[0] == alpha) & vm[0];
+                    const unsigned long long b1 = __ballot(T[1] == alpha) & vm[1];
+                    bpos = b0 ? __ffsll(b0) - 1 : (b1 ? kW + __ffsll(b1) - 1 : kNone);
+                    if (!(alpha < INFINITY)) bpos = kNone;
+                }
+                if (bpos == kNone) {  // no finite step: as Lawson-Hanson, nothing to remove
+#pragma unroll
+                    for (int s = 0; s < kPS; ++s) S.x[s] = S.z[s];
+                    break;
+                }
+#pragma unroll
+                for (int s = 0; s < kPS; ++s) S.x[s] = S.x[s] + alpha * (S.z[s] - S.x[s]);
                 STAMP(4);
                 int jj = bpos;
                 for (;;) {
@@ -1077,9 +1151,13 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             constexpr int rg = decltype(RG)::value;  // 0: rows i .. i + nb in LDS, 1: all in the slab, 2: decided per row
                             double nx[nb][si + 1];
                             double2 c2[nb];
+                            int mo[nb + 1];  // moff(i) .. moff(i + nb)
+                            mo[0] = moff(i);
+#pragma unroll
+                            for (int r = 0; r < nb; ++r) mo[r + 1] = moff(i + r + 1);  // (the recurrence moff(k + 1) = moff(k) + 8 (k / 8 + 1) measured 4 % slower: a dependent chain)
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
-                                const int nbase = moff(i + r + 1);
+                                const int nbase = mo[r + 1];
 #pragma unroll
                                 for (int s = 0; s <= si; ++s) {
                                     const int idx = nbase + cofs[s];
@@ -1091,7 +1169,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
                                 const double c_ = c2[r].x, s_ = c2[r].y;
-                                const int obase = moff(i + r);
+                                const int obase = mo[r];
 #pragma unroll
                                 for (int s = 0; s <= si; ++s) {
                                     if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(i + r - kW * s))) {
@@ -1304,13 +1382,13 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     }
                     S.p = pp - 1;
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
-                    int bad = kNone;
-#pragma unroll
-                    for (int s = kPS - 1; s >= 0; --s) {
-                        const int i = lane + kW * s;
-                        if (i < S.p && S.x[s] <= 0) bad = i;
+                    int bad;
+                    {
+                        const int pn = pp - 1;
+                        const unsigned long long b0 = __ballot(S.x[0] <= 0) & lanes_le(pn - 1);
+                        const unsigned long long b1 = pn > kW ? (__ballot(S.x[1] <= 0) & lanes_le(pn - 1 - kW)) : 0ull;
+                        bad = b0 ? __ffsll(b0) - 1 : (b1 ? kW + __ffsll(b1) - 1 : kNone);
                     }
-                    bad = wave_min_i(bad);
                     if (bad == kNone) break;
                     jj = bad;
                 }
@@ -1336,7 +1414,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             const int pe = __builtin_amdgcn_readfirstlane(S.p) < kLdsM ? __builtin_amdgcn_readfirstlane(S.p) : kLdsM;
             if (pe > 0) {  // the LDS rows only: the whole area in 16-byte stores (five per lane) instead of a store per row
                 const double2 zero2 = {0.0, 0.0};
-                for (int e = 2 * lane; e < kLdsMDoubles; e += 2 * kW) *reinterpret_cast<double2 *>(M.l + e) = zero2;
+                for (int e = 2 * lane; e < kLdsMDoubles; e += 2 * kW) *reinterpret_cast<double2 *>((double *)M.l + e) = zero2;
             }
         }
         // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
