@@ -561,16 +561,16 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
     double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
     const Win wl = load_win(lo), wh = load_win(hi);
     double t[kSlots];
-    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() {
-        band_eval4<false>(hb, wl, wh, rc, t);
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) t[s] = (binof(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
-    });
+    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() { band_eval4<false>(hb, wl, wh, rc, t); });
     lds_order();
     if (lane < kBMeas) rb[lane] = yreg - bx;
     // t by bin through xbuf: every gather of x has been issued, and the LDS executes a wave's instructions in order
     *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
     *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
+    lds_order();
+    // rows >= n of R do not exist: x is zero there, so only t_n and t_{n + 1} can be non-zero -- two stores instead of a
+    // select on every lane's four values
+    if (lane < 2) xbuf[2 + n + lane] = 0.0;
     lds_order();
     const Win ul = load_win(lo), uh = load_win(hi);
     lds_order();
@@ -735,32 +735,32 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #endif
     // column sums over a, delivered in position order (position 8 la + lb is column block K = la)
     a1[0] += reduce_scatter_a<NI>(rK, la);
-    // the new row (padded to the block boundary with zeros)
+    // the new row by position: -(l^T M) / lam in front of position p (beyond it l^T M is zero: those columns of M are), 1 / lam
+    // at p.  The masks are scalar (p is wave uniform): no vector compare, and the second register slot only where it is in use.
     {
         const int pbase = moff(p);
         const int width = 8 * ((p >> 3) + 1);
+        const int sp = p >> 6;
+        const unsigned long long bit = 1ull << (p & 63);
 #pragma unroll
         for (int s = 0; s < kPS; ++s) {
-            const int k = lane + kW * s;
-            if ((s == 0 || p >= kW) && k < width) M.st(p, pbase + k, k < p ? -a1[s] * ilam : (k == p ? ilam : 0.0));
+            if (s == 0 || p >= kW) {  // wave uniform
+                const unsigned long long at_p = s == sp ? bit : 0ull;
+                double rowv = -a1[s] * ilam;
+                if (__builtin_amdgcn_inverse_ballot_w64(at_p)) {
+                    rowv = ilam;
+                    S.x[s] = 0.0;
+                    S.q[s] = qn;
+                    S.pidx[s] = jmax;
+                }
+                if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
+                S.z[s] = fma(rowv, qn, S.x[s]);  // the rank-one update of the solution: z = x + row * qn (x_p = 0)
+            }
         }
-    }
-    // the rank-one update of the solution
-#pragma unroll
-    for (int s = 0; s < kPS; ++s) {
-        const int k = lane + kW * s;
-        if (k < p) {
-            const double r = -a1[s] * ilam;
-            S.z[s] = S.x[s] + r * qn;
-        } else if (k == p)
-            S.z[s] = qn * ilam;
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
         S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;  // scalar: jmax is wave uniform
-    put(S.q, p, qn, lane);
-    put(S.x, p, 0.0, lane);
-    put_i(S.pidx, p, jmax, lane);
     S.p = p + 1;
     return true;
 }
