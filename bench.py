@@ -78,12 +78,18 @@ def launch(args, argv) -> int:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import tempfile
+
+    procs, outs_f = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # a rank's stdout goes to a temporary file, not a pipe: nothing drains a pipe while the ranks are polled, and a rank
+        # that writes more than the pipe buffer holds would block in write() for ever
+        f = tempfile.TemporaryFile() if (r == 0 or args.launch_check) else None
+        outs_f.append(f)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 or args.launch_check else subprocess.DEVNULL))
+                                      stdout=f if f is not None else subprocess.DEVNULL))
     # poll every rank: the first one that exits non-zero ends the run (a rank that dies at start-up would otherwise leave
     # the others waiting in init_process_group / the barrier until the backend's own timeout)
     rc = 0
@@ -109,12 +115,108 @@ def launch(args, argv) -> int:
                 for q in alive:
                     procs[q].kill()
                 alive = set()
-    outs = [(p.stdout.read().decode() if p.stdout else "") for p in procs]
     for p in procs:
         p.wait()
+    outs = []
+    for f in outs_f:
+        if f is None:
+            outs.append("")
+        else:
+            f.seek(0)
+            outs.append(f.read().decode())
+            f.close()
     sys.stdout.write("".join(outs) if args.launch_check else outs[0])
     sys.stdout.flush()
     return rc
+
+
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _fmt_cpus(cpus):
+    c = sorted(cpus)
+    runs, i = [], 0
+    while i < len(c):
+        j = i
+        while j + 1 < len(c) and c[j + 1] == c[j] + 1:
+            j += 1
+        runs.append(str(c[i]) if i == j else f"{c[i]}-{c[j]}")
+        i = j + 1
+    return ",".join(runs)
+
+
+def gpu_numa_cpus(index):
+    """CPUs local to the `index`-th GPU, read from sysfs only (KFD topology -> PCI device -> local_cpulist): nothing here
+    touches the GPU, so it can run before the affinity is set and before HIP starts its helper threads."""
+    import glob
+
+    gpus = []
+    for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda q: int(os.path.basename(q))):
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(d, "properties")).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(props)
+    vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis:
+        try:
+            gpus = [gpus[int(v)] for v in vis.split(",") if v.strip() != ""]
+        except (ValueError, IndexError):
+            return None, None
+    if index >= len(gpus):
+        return None, None
+    loc, dom = int(gpus[index].get("location_id", "0")), int(gpus[index].get("domain", "0"))
+    bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+    base = f"/sys/bus/pci/devices/{bdf}"
+    try:
+        node = int(open(base + "/numa_node").read())
+        cpus = _cpulist(open(base + "/local_cpulist").read())
+    except (OSError, ValueError):
+        return None, None
+    return node, cpus
+
+
+def pin_rank_to_gpu_numa(local_rank, local_world, share_gpu=False):
+    """Restrict this rank (and every thread it starts later: the HIP runtime's, the library's IN / OUT / page-touch helpers) to
+    CPUs on the NUMA node of its GPU, in-process and before anything touches the GPU -- never through numactl / taskset
+    wrappers, which a profiler's preloaded library turns into an exec after GPU initialisation.  Ranks whose GPUs share a
+    node split that node's CPUs between them.  Returns what was done, for the bench line; never raises."""
+    try:
+        have = os.sched_getaffinity(0)
+    except AttributeError:
+        return {"cpus": None, "source": "no sched_getaffinity"}
+    try:
+        if os.environ.get("PNX_BENCH_NO_PIN") == "1":
+            return {"cpus": _fmt_cpus(have), "source": "PNX_BENCH_NO_PIN"}
+        dev = 0 if share_gpu else local_rank
+        node, local = gpu_numa_cpus(dev)
+        source = "gpu numa node (sysfs)"
+        if not local or not (local & have):
+            node, local, source = None, set(have), "affinity mask split by rank (no NUMA information)"
+        mine = sorted(local & have)
+        # ranks that land on the same CPU set take disjoint slices of it
+        peers = []
+        for r in range(local_world):
+            n2, l2 = (node, local) if (share_gpu or source.startswith("affinity")) else gpu_numa_cpus(r)
+            if l2 and sorted(l2 & have) == mine:
+                peers.append(r)
+        if local_rank in peers and len(peers) > 1 and len(mine) >= len(peers):
+            k = peers.index(local_rank)
+            per = len(mine) // len(peers)
+            mine = mine[k * per:(k + 1) * per] if k < len(peers) - 1 else mine[k * per:]
+        if mine:
+            os.sched_setaffinity(0, mine)
+        return {"cpus": _fmt_cpus(mine), "n_cpus": len(mine), "numa_node": node, "source": source}
+    except Exception as e:  # a bench must not fail over an affinity nicety
+        return {"cpus": None, "source": f"unpinned ({type(e).__name__})"}
 
 
 def volume_rows(workload, args, rank, world):
@@ -377,6 +479,54 @@ class NnlsLeg:
                           f"OpenMP over voxels, {dt:.2f} s"}
 
 
+def _gather_floats(vals, dist, device):
+    """[per-rank list of floats] on every rank."""
+    import torch
+
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [[float(x) for x in b.cpu()] for b in bufs]
+
+
+def host_mode_ranks(leg, dist, world, torch, n_total, reps=3):
+    """SURVEY 8(d)'s metric at N ranks: every rank hands ITS shard to the C ABI as host (numpy) arrays at the same moment
+    -- barrier, call, barrier -- so the ranks' uploads and downloads meet on the host's memory system as they would in a
+    node-wide fit.  value = voxels of the whole volume / median over reps of (max over ranks of the call time); per-rank
+    PCIe-inclusive GB/s and CPU sets are reported beside it."""
+    rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    y = leg.y.cpu().numpy()
+    if isinstance(leg, NnlsLeg):
+        call = lambda: leg.plan.solve(y, leg.cfg["max_iter"])
+        ref, key = leg.coeff, "coefficients"
+    else:
+        kw = dict(max_nfev=250, ftol=1e-8, jac=leg.jac, want_pcov=leg.want_pcov, device=leg.device.index)
+        call = lambda: leg.api.curvefit(leg.model, leg.b, y, leg.p0, leg.lo, leg.hi, **kw)
+        ref, key = leg.popt, "popt"
+    r = call()  # warm-up: staging slab / ring slots, first-touch of the helper threads
+    locals_ = []
+    for _ in range(reps):
+        del r  # the previous result is released before the clock starts
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        r = call()
+        locals_.append(time.perf_counter() - t)
+        dist.barrier()
+    nbytes = int(y.nbytes + sum(a.nbytes for a in r.values() if a is not None))
+    m = min(65536, ref.shape[-1] if key == "popt" else ref.shape[0])
+    got = torch.from_numpy(np.ascontiguousarray(r[key][..., :m] if key == "popt" else r[key][:m])).to(ref.device)
+    same = bool((got == (ref[..., :m] if key == "popt" else ref[:m])).all().item())
+    per_rank = _gather_floats(locals_ + [float(same), float(nbytes)], dist, rdev)
+    call_s = [max(pr[i] for pr in per_rank) for i in range(reps)]  # a rep ends when its slowest rank is home
+    dt = float(np.median(call_s))
+    return {"value": n_total / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "ms_reps": [c * 1e3 for c in call_s], "steps": reps,
+            "n_gpus": world, "per_rank_ms": [[x * 1e3 for x in pr[:reps]] for pr in per_rank],
+            "per_rank_pcie_GBps": [pr[reps + 1] / float(np.median(pr[:reps])) / 1e9 for pr in per_rank],
+            "pcie_GBps": sum(pr[reps + 1] for pr in per_rank) / dt / 1e9,
+            "equals_device_resident_result": all(pr[reps] == 1.0 for pr in per_rank)}
+
+
 def timed(leg, steps, warmup, world, dist, torch):
     for _ in range(warmup):
         leg.step()
@@ -569,6 +719,12 @@ def main(argv=None):
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # N > 1: this rank's threads (HIP's, the library's copy / page-touch helpers) stay on the NUMA node of its GPU; set before
+    # anything touches the GPU so that every later thread inherits it.  N = 1 keeps the box's own CPU share untouched.
+    affinity = None
+    if world > 1:
+        affinity = pin_rank_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.environ.get("PNX_BENCH_SHARE_GPU") == "1")
+
     import torch
 
     from pyneapple_amd import _lib
@@ -655,6 +811,8 @@ def main(argv=None):
         out["host_mode"] = leg.host_mode()
         if args.workload != "nnls":
             out["host_mode_f32"] = leg.host_mode_f32()
+    if world > 1 and not args.no_host_mode:  # every rank takes part (barriers)
+        out["host_mode"] = host_mode_ranks(leg, dist, world, torch, n_total)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = leg.cpu_baseline()
     if args.workload == "triexp" and not args.no_secondary:
@@ -685,6 +843,8 @@ def main(argv=None):
                                            "source": fl2["source"], "source_id": fl2["source_id"]}
         if solo and not args.no_host_mode:
             sec["host_mode"] = leg2.host_mode()
+        if world > 1 and not args.no_host_mode:
+            sec["host_mode"] = host_mode_ranks(leg2, dist, world, torch, n2)
         if solo and not args.no_cpu_baseline:
             sec["cpu_baseline"] = leg2.cpu_baseline()
         out["secondary"] = sec
@@ -700,12 +860,57 @@ def main(argv=None):
         out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
         out["roofline_mfma"] = mfma_roofline(device, torch)
     if world > 1:
+        aff = [None] * world
+        dist.all_gather_object(aff, affinity)
+        out["affinity"] = aff
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(finalize(out, args.workload)) + "\n").encode())
     return 0
+
+
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data")
+SCALAR_KEYS = ("nnls_voxels_per_s", "nnls_ms_per_step", "c3_host_voxels_per_s", "c4_host_voxels_per_s", "throughput_voxels_per_s")
+
+
+def finalize(out: dict, workload: str = "triexp") -> dict:
+    """The bench line in the order a truncating reader needs it: the contract's keys, then the five scalars of the metric's
+    other half (resident NNLS rate, both PCIe-inclusive rates, the two-in-flight throughput), then roofline / cpu_baseline,
+    then the detail objects; every prose string (`note`, `workload`, `mode`) moves to ONE trailing `notes` object keyed by its
+    path.  Pure function (tests/test_bench_line.py runs it on a committed line)."""
+    out = json.loads(json.dumps(out))  # deep copy, JSON types only
+    sec = out.get("secondary") or {}
+    nn = out if workload == "nnls" else sec
+    scal = {
+        "nnls_voxels_per_s": nn.get("value"), "nnls_ms_per_step": nn.get("ms_per_step"),
+        "c3_host_voxels_per_s": (out.get("host_mode") or {}).get("value") if workload == "triexp" else None,
+        "c4_host_voxels_per_s": (nn.get("host_mode") or {}).get("value"),
+        "throughput_voxels_per_s": (out.get("throughput") or {}).get("value"),
+    }
+    notes = {}
+
+    def strip(d, path):
+        for k in list(d.keys()):
+            v = d[k]
+            if isinstance(v, dict):
+                strip(v, path + [k])
+            elif k in ("note", "workload", "mode") and isinstance(v, str) and path and path != ["config"]:
+                notes[".".join(path + [k])] = d.pop(k)
+
+    strip(out, [])
+    final = {k: out[k] for k in HEAD_KEYS if k in out}
+    final.update(scal)
+    for k in ("roofline", "cpu_baseline", "config", "check"):
+        if k in out:
+            final[k] = out[k]
+    for k, v in out.items():
+        if k not in final:
+            final[k] = v
+    final["notes"] = notes
+    return final
 
 
 def nnls_traffic(n_vox):

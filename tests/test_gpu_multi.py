@@ -117,12 +117,14 @@ def test_plugin_n_gpus_shards_equal_the_single_device_fit(gpu, monkeypatch):
 
 def test_bench_two_ranks_as_child_processes_on_one_card():
     """bench.py --gpus 2 end to end: the launcher spawns two fresh ranks before anything touches the GPU, both put their
-    shard on device 0 (PNX_BENCH_SHARE_GPU), gloo carries the barrier and the max-reduce (no second card for RCCL)."""
+    shard on device 0 (PNX_BENCH_SHARE_GPU), gloo carries the barrier and the max-reduce (no second card for RCCL).  Since
+    round 4 the N > 1 line carries the PCIe-inclusive leg too: both ranks hand their shard to the ABI as numpy arrays at the
+    same moment (barrier-aligned), pinned to disjoint CPU sets, and get the device-resident results back bit for bit."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(PNX_BENCH_SHARE_GPU="1", PNX_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--voxels", "262144", "--steps", "2",
-                        "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-host-mode"], env=env,
-                       capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -132,3 +134,16 @@ def test_bench_two_ranks_as_child_processes_on_one_card():
     assert d["check"]["converged_frac"] > 0.995
     assert d["value"] > 0 and d["throughput"]["n_gpus"] == 2 and d["throughput"]["value"] > 0
     assert d["pipelined"]["results_identical_across_buffers"] is True
+    # the PCIe-inclusive leg of both workloads, every rank streaming its shard at once
+    for hm in (d["host_mode"], d["secondary"]["host_mode"]):
+        assert hm["n_gpus"] == 2 and hm["value"] > 0 and len(hm["per_rank_pcie_GBps"]) == 2 and min(hm["per_rank_pcie_GBps"]) > 0
+        assert hm["equals_device_resident_result"] is True
+    assert d["c3_host_voxels_per_s"] == d["host_mode"]["value"] and d["c4_host_voxels_per_s"] == d["secondary"]["host_mode"]["value"]
+    assert d["nnls_voxels_per_s"] == d["secondary"]["value"] > 0
+    # each rank reports the CPUs it pinned itself to; two ranks on one card take disjoint sets
+    aff = d["affinity"]
+    assert len(aff) == 2 and all(a and a.get("cpus") for a in aff)
+    assert aff[0]["cpus"] != aff[1]["cpus"]
+    head = lines[0][:1500]
+    for k in ("nnls_voxels_per_s", "nnls_ms_per_step", "c3_host_voxels_per_s", "c4_host_voxels_per_s", "throughput_voxels_per_s"):
+        assert f'"{k}": ' in head
