@@ -24,6 +24,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -106,11 +107,19 @@ static void tri_solve(const double *A, int m, const int *inds, int nsetp, double
     }
 }
 
-/* returns mode: 1 ok, -1 iteration limit */
+/* Test hook shared with the HIP block kernel (pnx_nnls_blk.hip, PNX_NNLS_TEST_REJECT=k,n): with nsetp % k == k - 1 the first n
+ * candidates of an outer iteration are rejected unseen, so that the kernel's bookkeeping of rejected columns -- which the
+ * reference workload never exercises -- can be checked against this restatement.  The kernel's list holds eight columns; a
+ * ninth rejection hands the voxel to its general kernel, which knows no hook: mode -2 asks the caller to solve the voxel again
+ * without it. */
+static int g_rej_k = 0, g_rej_n = 0;
+#define PNX_ORACLE_MAX_REJ 8
+
+/* returns mode: 1 ok, -1 iteration limit, -2 (hook only) solve again without the hook */
 static int nnls_one(double *A, int m, int n, double *b, int maxiter, double *x, double *rnorm, int *iters,
-                    double *w, double *zz, double *work, int *inds)
+                    double *w, double *zz, double *work, int *inds, int rej_k, int rej_n)
 {
-    int iz1 = 0, nsetp = 0, iteration = 0, skip = 0, izmax = 0;
+    int iz1 = 0, nsetp = 0, iteration = 0, skip = 0, izmax = 0, nrej = 0;
     for (int j = 0; j < n; ++j) {
         x[j] = 0;
         w[j] = 0;
@@ -137,6 +146,7 @@ static int nnls_one(double *A, int m, int n, double *b, int maxiter, double *x, 
             }
         }
         if (wmax <= 0) break;
+        if (rej_k > 0 && nsetp >= 128) return -2; /* hook: the block kernel hands voxels with more than 128 passive bins over, too */
         int iz = izmax, j = inds[iz];
 
         int len = m - nsetp;
@@ -148,17 +158,21 @@ static int nnls_one(double *A, int m, int n, double *b, int maxiter, double *x, 
         unorm = sqrt(unorm);
         double ztest = 0;
         int accept = 0;
-        if (((unorm + fabs(beta) * 0.01) - unorm) > 0) {
+        const int forced = rej_k > 0 && (nsetp % rej_k) == rej_k - 1 && nrej < rej_n;
+        if (!forced && ((unorm + fabs(beta) * 0.01) - unorm) > 0) {
             memcpy(zz, b, sizeof(double) * m);
             house_apply(work, tau, len, zz + nsetp);
             ztest = zz[nsetp] / beta;
             if (ztest > 0) accept = 1;
         }
         if (!accept) {
+            if (rej_k > 0 && nrej >= PNX_ORACLE_MAX_REJ) return -2;
+            nrej += 1;
             w[j] = 0;
             skip = 1;
             continue;
         }
+        nrej = 0;
         /* column j enters the passive set */
         memcpy(b, zz, sizeof(double) * m);
         inds[iz] = inds[iz1];
@@ -256,6 +270,11 @@ int pnxo_nnls_batch(long n_vox, int n_meas, int n_bins, const double *basis, con
     if (n_meas < 1 || n_bins < 1 || n_reg < 0) return -1;
     const int m = n_meas + n_reg, n = n_bins;
     if (!max_iter) max_iter = 3 * n;
+    g_rej_k = g_rej_n = 0;
+    {
+        const char *t = getenv("PNX_NNLS_TEST_REJECT");
+        if (t && (sscanf(t, "%d,%d", &g_rej_k, &g_rej_n) != 2 || g_rej_k < 1 || g_rej_n < 1)) g_rej_k = g_rej_n = 0;
+    }
     /* column-major master copy of A */
     double *A0 = (double *)malloc(sizeof(double) * (size_t)m * n);
     if (!A0) return -2;
@@ -294,7 +313,13 @@ int pnxo_nnls_batch(long n_vox, int n_meas, int n_bins, const double *basis, con
                 st = -2; /* asarray_chkfinite -> ValueError -> failure path */
             } else {
                 memcpy(A, A0, sizeof(double) * (size_t)m * n);
-                int mode = nnls_one(A, m, n, b, max_iter, x, &rn, &it, w, zz, work, inds);
+                int mode = nnls_one(A, m, n, b, max_iter, x, &rn, &it, w, zz, work, inds, g_rej_k, g_rej_n);
+                if (mode == -2) { /* hook: the kernel's hand-over to its general kernel */
+                    memcpy(A, A0, sizeof(double) * (size_t)m * n);
+                    for (int i = 0; i < n_meas; ++i) b[i] = yv[i];
+                    for (int i = n_meas; i < m; ++i) b[i] = 0;
+                    mode = nnls_one(A, m, n, b, max_iter, x, &rn, &it, w, zz, work, inds, 0, 0);
+                }
                 st = (mode == 1) ? 1 : 0;
             }
             double *cv = coeff + (size_t)vx * n;

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "pnx_internal.hpp"
@@ -88,6 +89,7 @@ struct BlkArgs {
     int n_meas, n_bins, n_reg, max_iter;
     double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] (mu included)
     int rhb;       // half bandwidth, 1 or 2
+    int test_rej_k, test_rej_n;  // test hook (PNX_NNLS_TEST_REJECT=k,n): with p % k == k - 1 the first n candidates of an outer iteration are rejected unseen
 };
 
 // -DPNX_NNLS_BLK_CHECK: every index into the slab of M / a row of G is range checked; the first violation is reported with
@@ -354,6 +356,7 @@ __device__ __forceinline__ void bt_times(const double *Bl, const double *v, int 
 }
 
 #ifdef PNX_NNLS_STAMP
+__device__ unsigned long long g_blk_rejects = 0;  // rejected candidate columns since the library was loaded (diagnostic builds)
 #define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
 #define COUNT(k, v) do { cnt[k] += (v); } while (0)
 #else
@@ -395,6 +398,7 @@ struct VoxState {
     double q[kPS], x[kPS], z[kPS];  // by position
     int pidx[kPS];                  // bin of a position
     unsigned long long inP[kSlots];  // by bin, as wave masks in scalar registers (bit l of inP[s]: bin binof(l, s)); bins >= n_bins count as taken
+    int nrej;                        // columns rejected in this outer iteration (their inP bits are set meanwhile; the bins wait in LDS)
     int p;
 };
 
@@ -766,35 +770,57 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 }
 
 #if PNX_BLK_DUAL2
-// The candidate loop of an outer iteration: largest positive dual (ties: lowest bin), append, or zero the dual of a rejected
-// column and look again.  Returns false when no column entered (KKT satisfied).
+constexpr int kMaxRej = 8;  // rejected columns an outer iteration can remember (the four spare doubles behind xbuf's halo)
+// The candidate step of an outer iteration: largest positive dual (ties: lowest bin), then the append.  Returns 0 when no dual
+// is positive (KKT satisfied), 1 when the column entered, 2 when it was rejected, 3 when it was rejected and the list is full.
+// A rejected column is what Lawson-Hanson answers with "w_j = 0, take the next largest".  It is rare (none in 28 000 outer
+// iterations of the reference workload), so it is not worth a loop around the append -- a loop keeps w[] and a copy of the
+// voxel state alive across the append and lets the compiler hoist the append's addresses in front of it: 64 bytes of scratch
+// per lane written in every outer iteration, which on this chip is HBM traffic.  Instead the column's passive flag is set for
+// the time being, its bin is remembered in LDS, and the outer loop evaluates the dual again (same state, same values; the
+// flag masks the column); the flags are taken back when a column enters.
 template <int NI>
-__device__ __forceinline__ bool candidate(const double *G, const MRef &M, const lds_int *ps, int lc, double (&w)[kSlots], VoxState &S) {
+__device__ __forceinline__ int candidate(const double *G, const MRef &M, const lds_int *ps, lds_int *rejlist, int lc, const double (&w)[kSlots],
+                                         VoxState &S) {
     const int la = lc >> 3, lb = lc & 7;
     unsigned goff[NI];
     append_prefetch<NI>(ps, lb, goff);
-    for (;;) {
-        const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-        if (!(best > 0)) return false;  // KKT satisfied
-        // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
-        int jmax;
-        {
-            const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
-            const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
-            const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
-            const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
-            const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
-            const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
-            const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
-            jmax = lo < hi ? lo : hi;
-        }
-        if (jmax == kNone) return false;  // cannot happen (some lane holds the maximum); never index G with it
-        if (try_append<NI>(G, M, ps, lc, la, lb, jmax, best, S, goff)) return true;
-        // reject: w[j] = 0 and look for the next largest
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s)
-            if (binof(lc, s) == jmax) w[s] = 0.0;
+    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
+    if (!(best > 0)) return 0;  // KKT satisfied
+    // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
+    int jmax;
+    {
+        const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
+        const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
+        const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
+        const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
+        const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
+        const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
+        const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
+        jmax = lo < hi ? lo : hi;
     }
+    if (jmax == kNone) return 0;  // cannot happen (some lane holds the maximum); never index G with it
+    // test hook: reject valid columns, so that the bookkeeping of rejected columns runs although the reference workload never
+    // rejects one (the minimiser is unique with a regulariser: the solve must arrive at the same spectrum by another path)
+    const int tk = kargs()->test_rej_k;
+    const bool forced = tk > 0 && (__builtin_amdgcn_readfirstlane(S.p) % tk) == tk - 1 && __builtin_amdgcn_readfirstlane(S.nrej) < kargs()->test_rej_n;
+    if (!forced && try_append<NI>(G, M, ps, lc, la, lb, jmax, best, S, goff)) {
+        const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
+        for (int k = 0; k < nr; ++k) {  // the columns rejected meanwhile may be looked at again
+            const int j = __builtin_amdgcn_readfirstlane(rejlist[k]);
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) S.inP[s] &= ~((s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull);
+        }
+        S.nrej = 0;
+        return 1;
+    }
+    const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
+    if (nr >= kMaxRej) return 3;
+    if (lc == 0) rejlist[nr] = jmax;
+    S.nrej = nr + 1;
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;
+    return 2;
 }
 #endif
 
@@ -907,7 +933,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         const int ml = lane & 31;
         const double yreg = ml < nm ? yv[ml] : 0.0;
         const bool finite = __all(isfinite(yreg) ? 1 : 0) != 0;
-        const double yn2 = wave_sum(lane < kBMeas ? yreg * yreg : 0.0);
         VoxState S;
 #pragma unroll
         for (int s = 0; s < kPS; ++s) {
@@ -919,6 +944,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) S.inP[s] = __ballot(binof(lane, s) >= n);
         S.p = 0;
+        S.nrej = 0;
         int iteration = 0, status = finite ? 1 : -2;
         double w[kSlots];
         STAMP(0);
@@ -973,12 +999,24 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
                     const int lc = fresh(lane);
                     const double *Gp = kargs()->G;
+                    lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);  // the four spare doubles behind the halo
+                    int r;
                     if (nI <= 2)
-                        accepted = candidate<2>(Gp, M, ps, lc, w, S);
+                        r = candidate<2>(Gp, M, ps, rejlist, lc, w, S);
                     else if (nI <= 4)
-                        accepted = candidate<4>(Gp, M, ps, lc, w, S);
+                        r = candidate<4>(Gp, M, ps, rejlist, lc, w, S);
                     else
-                        accepted = candidate<6>(Gp, M, ps, lc, w, S);
+                        r = candidate<6>(Gp, M, ps, rejlist, lc, w, S);
+                    r = __builtin_amdgcn_readfirstlane(r);
+                    if (r == 2) {
+                        COUNT(2, 1);
+#ifdef PNX_NNLS_STAMP
+                        if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
+#endif
+                        continue;  // a rejected column: its flag is set, the dual is evaluated again
+                    }
+                    if (r == 3) status = kBail;  // more rejections in one outer iteration than the list holds: the general kernel
+                    accepted = r == 1;
                 }
             }
 #else
@@ -1456,7 +1494,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             const double r = lane < kBMeas ? yreg - bx : 0.0;
             rn = sqrt(wave_sum(fma(r, r, tt)));
         } else
-            rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
+            rn = sqrt(wave_sum(lane < kBMeas ? yreg * yreg : 0.0));  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
         {
             KArgs *K = kargs();
             if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
@@ -1480,6 +1518,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
 #ifdef PNX_NNLS_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 7)
         printf("STAMP setup=%llu dual_bx=%llu dual_bt=%llu dual_reg=%llu cand+append=%llu sync=%llu alpha=%llu removal_head=%llu removal_rows=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[9], seg[10], seg[1], seg[2], seg[3], seg[4], seg[11], seg[5], seg[6], seg[7], seg[8]);
+    if (threadIdx.x == 0 && blockIdx.x == 0) printf("REJECTS so far=%llu\n", g_blk_rejects);
     if (threadIdx.x == 0 && blockIdx.x == 7)
         printf("COUNT voxels=%lld outer=%lld rejects=%lld removals=%lld rot_rows=%lld sum_p=%lld p_gt48=%lld p_gt64=%lld\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]);
 #endif
@@ -1562,6 +1601,10 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         a.max_iter = max_iter;
         for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
         a.rhb = P->rhb;
+        a.test_rej_k = a.test_rej_n = 0;
+        if (const char *t = getenv("PNX_NNLS_TEST_REJECT")) {
+            if (sscanf(t, "%d,%d", &a.test_rej_k, &a.test_rej_n) != 2 || a.test_rej_k < 1 || a.test_rej_n < 1) a.test_rej_k = a.test_rej_n = 0;
+        }
         PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
         long long grid = (c + kBlkWaves - 1) / kBlkWaves;
         if (grid > P->blk_groups) grid = P->blk_groups;

@@ -176,6 +176,40 @@ def test_full_size_kkt_c4(gpu):
         torch.testing.assert_close(rnorm[bad], torch.linalg.norm(y[bad], dim=1))
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_rejected_candidate_columns_are_set_aside_and_come_back(gpu, oracle, monkeypatch, order):
+    """Lawson-Hanson answers a rejected candidate with "w_j = 0, take the next largest" (and stops where nothing positive is
+    left).  The block kernel has no loop around its append for that: it sets the column's passive flag, remembers the bin in LDS,
+    evaluates the dual again and takes the flags back when a column enters; a ninth rejection in one outer iteration hands the
+    voxel to the general kernel.  The reference workload never rejects a column (none in 400 fuzz cases either), so a test hook
+    shared by kernel and oracle (PNX_NNLS_TEST_REJECT=k,n: with p % k == k - 1 the first n candidates of an outer iteration are
+    rejected unseen) forces the path: the kernel must follow the oracle's detours column by column."""
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, reg_order=order)
+    _, basis, reg = synth.nnls_matrices(32, cfg)
+    _, y, _ = synth.make_numpy("tri_reduced", 768, 32, sigma=0.01, seed=5, scale=1000.0)
+    plain = gpu.nnls(basis, reg, y, 2000)
+    assert (plain["status"] == 1).all()
+    changed = 0
+    for hook in ("3,1", "2,4", "1,2", "5,8", "4,9"):  # the last one overflows the list of eight: hand-over to the general kernel
+        monkeypatch.setenv("PNX_NNLS_TEST_REJECT", hook)
+        r = gpu.nnls(basis, reg, y, 2000)
+        o = oracle.nnls(basis, reg, y, 2000, n_threads=8)
+        np.testing.assert_array_equal(r["status"], o["status"], err_msg=hook)
+        ok = o["status"] == 1
+        assert _scaled_err(r["coefficients"][ok], o["coefficients"][ok]).max() < 1e-6, hook
+        np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9, err_msg=hook)
+        assert (r["iters"] == o["iters"]).mean() > 0.99, hook
+        assert (((r["coefficients"] > 0) != (o["coefficients"] > 0)).sum(axis=1) == 0).mean() > 0.99, hook
+        changed += int((r["iters"] != plain["iters"]).any() or (r["coefficients"] != plain["coefficients"]).any())
+    assert changed >= 3  # the hook did send the solves down other paths
+    monkeypatch.delenv("PNX_NNLS_TEST_REJECT")
+    again = gpu.nnls(basis, reg, y, 2000)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(again[k], plain[k])
+
+
 def test_host_chunks_defer_the_hand_over_pass(gpu, monkeypatch):
     """Host arrays in several chunks: the block kernel's handed-over voxels (passive set beyond 128 positions) are solved in
     ONE pass at the end of the call and patched into the result arrays.  Same bits as the single-chunk call (hand-over pass
