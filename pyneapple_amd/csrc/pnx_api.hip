@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "pnx_curvefit_kernel.hpp"
+#include "pnx_host_pipeline.hpp"
 #include "pnx_internal.hpp"
 #include "pnx_nnls.hpp"
 
@@ -27,10 +28,13 @@ static thread_local char g_err[512] = "";
 int set_error(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    char tmp[sizeof(g_err)];  // the format arguments may point into g_err (a message passed on from another thread)
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
     va_end(ap);
+    memcpy(g_err, tmp, sizeof(g_err));
     return code;
 }
+const char *last_error_text() { return g_err; }
 
 #define PNX_HIP(call)                                                                              \
     do {                                                                                           \
@@ -88,177 +92,31 @@ struct DevBuf {
 };
 
 
-// ---- host-staging pipeline ------------------------------------------------------------------------------------
-// PNX_MEM_HOST calls hand over pageable numpy memory.  The volume is cut into chunks of voxels that flow through a
-// ring of device slots, one stage per host thread:
-//   IN      blocking H2D copy of chunk k into slot k % S (waits for the slot to be drained)
-//   LAUNCH  (the calling thread) enqueues the kernels of chunk k, alternating between the kernel streams so that the
-//           drain tail of one chunk overlaps the start of the next; records an event
-//   OUT     waits for the event, blocking D2H copy of chunk k into the caller's arrays
-//   TOUCH   helper threads take the first-touch page faults of the freshly allocated result arrays ahead of OUT
-//           (42 ms per GB when they are taken serially inside the D2H copy)
-// so H2D, compute, D2H and the page faults overlap; the call returns when every stage has drained.
-struct PipeOps {
-    std::function<int(int k, int slot, hipStream_t st)> h2d, launch, d2h;
-    std::function<void(int k)> touch;  // may be empty
+// ---- host-staging pipeline: pnx_host_pipeline.hpp on the HIP runtime ------------------------------------------
+struct HipBackend {
+    typedef hipStream_t stream_t;
+    typedef hipEvent_t event_t;
+    static bool bind_device(int device) { return hipSetDevice(device) == hipSuccess; }
+    // kernel streams at the lowest priority: hardware queues are pooled per priority, so a copy never sits in a queue
+    // behind a chunk's kernel (see curvefit_streamed)
+    static bool stream_create(stream_t *s, bool kernel) {
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) return false;
+        const int prio_other = prio_least > 0 ? 0 : prio_greatest;
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, kernel ? prio_least : prio_other) == hipSuccess;
+    }
+    static void stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+    static bool stream_sync(stream_t s) { return hipStreamSynchronize(s) == hipSuccess; }
+    static bool event_create(event_t *e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; }
+    static void event_destroy(event_t e) { (void)hipEventDestroy(e); }
+    static bool event_record(event_t e, stream_t s) { return hipEventRecord(e, s) == hipSuccess; }
+    static bool event_sync(event_t e) { return hipEventSynchronize(e) == hipSuccess; }
 };
+typedef PipeOpsT<hipStream_t> PipeOps;
 
 static int run_pipeline(int n_chunks, int n_slots, int k_streams, int touchers, int device, hipStream_t user_stream,
                         const PipeOps &ops) {
-    if (n_chunks == 1) {  // small batch: everything on the caller's stream, no threads
-        int rc = ops.h2d(0, 0, user_stream);
-        if (!rc) rc = ops.launch(0, 0, user_stream);
-        if (rc) return rc;
-        if (ops.touch) ops.touch(0);
-        PNX_HIP(hipStreamSynchronize(user_stream));
-        rc = ops.d2h(0, 0, user_stream);
-        if (rc) return rc;
-        PNX_HIP(hipStreamSynchronize(user_stream));
-        return PNX_OK;
-    }
-    if (user_stream) PNX_HIP(hipStreamSynchronize(user_stream));
-    const bool trace = getenv("PNX_HOST_TRACE") != nullptr;
-    const auto t_call = std::chrono::steady_clock::now();
-    auto now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    std::vector<double> t_in(n_chunks), t_launch(n_chunks), t_kdone(n_chunks), t_out(n_chunks), t_touch(n_chunks);
-    struct Shared {
-        std::mutex mu;
-        std::condition_variable cv;
-        int in_done = 0, launched = 0, drained = 0;
-        int code = PNX_OK;
-        std::string msg;
-        bool failed = false;
-    } sh;
-    std::atomic<bool> stop(false);
-    auto fail = [&](int code) {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        if (!sh.failed) {
-            sh.failed = true;
-            sh.code = code;
-            sh.msg = g_err;  // the failing thread's message
-        }
-        stop.store(true);
-        sh.cv.notify_all();
-    };
-    hipStream_t s_in = nullptr, s_out = nullptr, s_k[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> ev(n_chunks, nullptr);
-    auto cleanup = [&]() {
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_out) (void)hipStreamDestroy(s_out);
-        for (auto &q : s_k)
-            if (q) (void)hipStreamDestroy(q);
-        for (auto &e : ev)
-            if (e) (void)hipEventDestroy(e);
-    };
-    {
-        // kernel streams at the lowest priority: hardware queues are pooled per priority, so a copy never sits in a queue
-        // behind a chunk's kernel (see curvefit_streamed)
-        int prio_least = 0, prio_greatest = 0;
-        hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        const int prio_other = prio_least > 0 ? 0 : prio_greatest;
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s_in, hipStreamNonBlocking, prio_other);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s_out, hipStreamNonBlocking, prio_other);
-        for (int i = 0; i < k_streams && e == hipSuccess; ++i) e = hipStreamCreateWithPriority(&s_k[i], hipStreamNonBlocking, prio_least);
-        for (int k = 0; k < n_chunks && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-        if (e != hipSuccess) {
-            cleanup();
-            return set_error(PNX_ERR_HIP, "pipeline stream/event setup: %s", hipGetErrorString(e));
-        }
-    }
-    // claim[k]: 0 untouched, 1 being touched / touched by a helper, 2 taken by OUT without touching
-    std::vector<std::atomic<int>> claim(n_chunks), touched(n_chunks);
-    for (int k = 0; k < n_chunks; ++k) {
-        claim[k].store(0);
-        touched[k].store(0);
-    }
-    std::vector<std::thread> th;
-    th.emplace_back([&]() {  // IN
-        if (hipSetDevice(device) != hipSuccess) return fail(set_error(PNX_ERR_HIP, "hipSetDevice failed (IN thread)"));
-        for (int k = 0; k < n_chunks; ++k) {
-            {
-                std::unique_lock<std::mutex> lk(sh.mu);
-                sh.cv.wait(lk, [&] { return sh.failed || sh.drained > k - n_slots; });
-                if (sh.failed) return;
-            }
-            int rc = ops.h2d(k, k % n_slots, s_in);
-            if (!rc && hipStreamSynchronize(s_in) != hipSuccess) rc = set_error(PNX_ERR_HIP, "H2D of chunk %d failed", k);
-            if (rc) return fail(rc);
-            t_in[k] = now();
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.in_done = k + 1;
-            sh.cv.notify_all();
-        }
-    });
-    th.emplace_back([&]() {  // OUT
-        if (hipSetDevice(device) != hipSuccess) return fail(set_error(PNX_ERR_HIP, "hipSetDevice failed (OUT thread)"));
-        for (int k = 0; k < n_chunks; ++k) {
-            {
-                std::unique_lock<std::mutex> lk(sh.mu);
-                sh.cv.wait(lk, [&] { return sh.failed || sh.launched > k; });
-                if (sh.failed) return;
-            }
-            if (ops.touch) {
-                int expect = 0;
-                if (claim[k].compare_exchange_strong(expect, 1)) {  // no helper got here yet: touch it ourselves
-                    ops.touch(k);
-                    touched[k].store(1);
-                } else {
-                    while (!touched[k].load()) std::this_thread::yield();
-                }
-            }
-            int rc = PNX_OK;
-            t_touch[k] = now();
-            if (hipEventSynchronize(ev[k]) != hipSuccess) rc = set_error(PNX_ERR_HIP, "kernel of chunk %d failed", k);
-            t_kdone[k] = now();
-            if (!rc) rc = ops.d2h(k, k % n_slots, s_out);
-            if (!rc && hipStreamSynchronize(s_out) != hipSuccess) rc = set_error(PNX_ERR_HIP, "D2H of chunk %d failed", k);
-            if (rc) return fail(rc);
-            t_out[k] = now();
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.drained = k + 1;
-            sh.cv.notify_all();
-        }
-    });
-    if (ops.touch)
-        for (int t = 0; t < touchers; ++t)
-            th.emplace_back([&]() {
-                for (int k = 0; k < n_chunks; ++k) {
-                    if (stop.load()) return;
-                    int expect = 0;
-                    if (claim[k].compare_exchange_strong(expect, 1)) {
-                        ops.touch(k);
-                        touched[k].store(1);
-                    }
-                }
-            });
-    // LAUNCH stage on the calling thread
-    for (int k = 0; k < n_chunks; ++k) {
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            sh.cv.wait(lk, [&] { return sh.failed || sh.in_done > k; });
-            if (sh.failed) break;
-        }
-        hipStream_t st = s_k[k % k_streams];
-        int rc = ops.launch(k, k % n_slots, st);
-        if (!rc && hipEventRecord(ev[k], st) != hipSuccess) rc = set_error(PNX_ERR_HIP, "hipEventRecord failed");
-        if (rc) {
-            fail(rc);
-            break;
-        }
-        t_launch[k] = now();
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.launched = k + 1;
-        sh.cv.notify_all();
-    }
-    for (auto &t : th) t.join();
-    for (int i = 0; i < k_streams; ++i) (void)hipStreamSynchronize(s_k[i]);  // nothing of ours may outlive the call
-    cleanup();
-    if (trace)
-        for (int k = 0; k < n_chunks; ++k)
-            fprintf(stderr, "[pnx host] chunk %d: h2d_done %.1f launched %.1f out_ready %.1f kernel_done %.1f d2h_done %.1f ms\n", k, t_in[k],
-                    t_launch[k], t_touch[k], t_kdone[k], t_out[k]);
-    if (sh.failed) return set_error(sh.code, "%s", sh.msg.c_str());
-    return PNX_OK;
+    return run_pipeline_t<HipBackend>(n_chunks, n_slots, k_streams, touchers, device, user_stream, ops, getenv("PNX_HOST_TRACE") != nullptr);
 }
 
 // write one byte per page of [p, p + bytes): first-touch faults taken here, in parallel with the running kernel,
@@ -536,6 +394,10 @@ struct StreamRes {
 };
 static StreamRes g_sres[64];
 static bool g_sres_busy[64] = {false};
+// A streamed launch whose watermark did not move (another library's streams share the hardware queue of the upload, DESIGN
+// section 5) is an environmental condition that will hold for the next call too: the device's host-array fits then go through
+// the chunk ring for the next PNX_STREAM_COOLDOWN calls (or until pnx_release_staging) instead of paying the stall every time.
+static std::atomic<int> g_stream_cooldown[64];
 
 struct StreamLease {
     StreamRes *r = nullptr;
@@ -622,14 +484,14 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
         ctl = (StreamCtl *)c.take(ctl_bytes);
         if (pass == 0 && res.ensure_slab(c.off)) return kStreamRetry;  // no room for the whole volume: the ring needs three chunks
     }
-    // pinned host: granule flags (written by the kernel), watermark values (source of the 8-byte copies), the abort word
-    const size_t pin_bytes = sizeof(unsigned long long) * (size_t)(n_in + 1) + sizeof(unsigned int) * (size_t)n_gran;
+    // pinned host: watermark values (source of the 8-byte copies), granule flags (written by the kernel) and, behind them, the
+    // abort word the kernel polls while it waits for the watermark (a plain host store raises it: no stream is involved)
+    const size_t pin_bytes = sizeof(unsigned long long) * (size_t)(n_in + 1) + sizeof(unsigned int) * (size_t)(n_gran + 1);
     if (res.ensure_pin(pin_bytes)) return kStreamRetry;  // no pinned memory to be had: the ring does without
     memset(res.pin, 0, pin_bytes);
-    unsigned long long *wm = (unsigned long long *)res.pin;  // [n_in], then one word holding the abort value
-    unsigned int *abort_src = (unsigned int *)(wm + n_in);
-    *abort_src = 1u;
+    unsigned long long *wm = (unsigned long long *)res.pin;  // [n_in] (+ one spare word)
     volatile unsigned int *flags = (volatile unsigned int *)(wm + n_in + 1);
+    unsigned int *abort_word = (unsigned int *)(flags + n_gran);
     unsigned int *flags_dev = nullptr;
     PNX_HIP(hipHostGetDevicePointer((void **)&flags_dev, (void *)flags, 0));
 
@@ -645,7 +507,8 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     sl.ctl = ctl;
     sl.host_flags = flags_dev;
     sl.granule_shift = gshift;
-    sl.spins = (unsigned int)env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 30);  // ~6 us per poll
+    sl.spins = (unsigned int)env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 20);  // ~6 us per poll: 2.4 s, at most ~6 s (the host's own
+                                                                                   // watchdog below gives up after PNX_STREAM_STALL_MS)
     sl.phase = 1;
     rc = curvefit_device(o, (int64_t)nv, bd, dy, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, dpopt, dpcov, dstat,
                          dnfev, dcost, dev, s_main, &sl);
@@ -653,24 +516,10 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     if (rc) return rc;
     const double t_launched = now();
 
-    std::atomic<bool> failed(false), kernel_done(false);
-    std::mutex err_mu;
-    int err_code = PNX_OK;
-    std::string err_msg;
-    auto fail = [&](int code) {
-        std::lock_guard<std::mutex> lk(err_mu);
-        if (!failed.load()) {
-            err_code = code;
-            err_msg = g_err;
-            failed.store(true);
-        }
-    };
-    std::vector<double> t_in(n_in), t_flag(n_gran), t_out(n_gran);
-    std::vector<std::atomic<int>> claim(n_gran), touched(n_gran);
-    for (int g = 0; g < n_gran; ++g) {
-        claim[g].store(0);
-        touched[g].store(0);
-    }
+    // the first watermark move, observed on the device: an event behind it on the upload stream
+    hipEvent_t ev_first = nullptr;
+    PNX_HIP(hipEventCreateWithFlags(&ev_first, hipEventDisableTiming));
+    std::atomic<int> first_recorded(0);
     auto touch = [&](int g) {
         const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
         for (int j = 0; j < n; ++j) touch_pages(popt + j * nv + v0, c * sizeof(T));
@@ -679,132 +528,109 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
         if (nfev) touch_pages(nfev + v0, c * sizeof(int32_t));
         if (cost) touch_pages(cost + v0, c * sizeof(T));
     };
-    std::vector<std::thread> th;
-    th.emplace_back([&]() {  // IN
-        auto body = [&]() -> int {
-            PNX_HIP(hipSetDevice(device));
-            if (const int ms = env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000))  // tests: a stalled upload
-                std::this_thread::sleep_for(std::chrono::milliseconds(ms));
-            for (int i = 0; i < n_in && !failed.load(); ++i) {
-                const size_t v0 = (size_t)i * in_piece, c = std::min(in_piece, nv - v0);
-                PNX_HIP(hipMemcpyAsync(ty + v0 * n_b, y + v0 * n_b, c * n_b * sizeof(T), hipMemcpyHostToDevice, s_in));
-                if constexpr (F32) {
-                    int r = cvt(ty + v0 * n_b, dy + v0 * n_b, c * n_b, s_in);
-                    if (r) return r;
-                }
-                if (pv) {  // parameter-major (n_free, n_vox) start values and bounds: one row slice per parameter and array
-                    const T *src[3] = {p0_pv, lo_pv, hi_pv};
-                    T *tdst[3] = {tp0, tlo, thi};
-                    double *ddst[3] = {dp0, dlo, dhi};
-                    for (int a3 = 0; a3 < 3; ++a3)
-                        for (int j = 0; j < n; ++j) {
-                            PNX_HIP(hipMemcpyAsync(tdst[a3] + j * nv + v0, src[a3] + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
-                            if constexpr (F32) {
-                                int r = cvt(tdst[a3] + j * nv + v0, ddst[a3] + j * nv + v0, c, s_in);
-                                if (r) return r;
-                            }
-                        }
-                }
-                for (int j = 0; j < n_fpv; ++j) {  // parameter-major (n_fixed, n_vox): one row slice per fixed parameter
-                    PNX_HIP(hipMemcpyAsync(tfx + j * nv + v0, fixed_pv + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
+    StreamedOps ops;
+    ops.bind_device = [&]() { return hipSetDevice(device) == hipSuccess; };
+    ops.upload_piece = [&](int i) -> int {
+        const size_t v0 = (size_t)i * in_piece, c = std::min(in_piece, nv - v0);
+        PNX_HIP(hipMemcpyAsync(ty + v0 * n_b, y + v0 * n_b, c * n_b * sizeof(T), hipMemcpyHostToDevice, s_in));
+        if constexpr (F32) {
+            int r = cvt(ty + v0 * n_b, dy + v0 * n_b, c * n_b, s_in);
+            if (r) return r;
+        }
+        if (pv) {  // parameter-major (n_free, n_vox) start values and bounds: one row slice per parameter and array
+            const T *src[3] = {p0_pv, lo_pv, hi_pv};
+            T *tdst[3] = {tp0, tlo, thi};
+            double *ddst[3] = {dp0, dlo, dhi};
+            for (int a3 = 0; a3 < 3; ++a3)
+                for (int j = 0; j < n; ++j) {
+                    PNX_HIP(hipMemcpyAsync(tdst[a3] + j * nv + v0, src[a3] + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
                     if constexpr (F32) {
-                        int r = cvt(tfx + j * nv + v0, dfx + j * nv + v0, c, s_in);
+                        int r = cvt(tdst[a3] + j * nv + v0, ddst[a3] + j * nv + v0, c, s_in);
                         if (r) return r;
                     }
                 }
-                wm[i] = v0 + c;
-                PNX_HIP(hipMemcpyAsync(&ctl->ready, &wm[i], sizeof(unsigned long long), hipMemcpyHostToDevice, s_in));
-                t_in[i] = now();
-            }
-            PNX_HIP(hipStreamSynchronize(s_in));
-            return PNX_OK;
-        };
-        const int r = body();
-        if (r) {
-            fail(r);
-            // tell the kernel to stop waiting (best effort: its own poll limit ends the wait otherwise)
-            (void)hipMemcpyAsync(&ctl->abort, abort_src, sizeof(unsigned int), hipMemcpyHostToDevice, s_in);
-            (void)hipStreamSynchronize(s_in);
         }
-    });
-    for (int ot = 0; ot < n_out; ++ot) th.emplace_back([&, ot]() {  // OUT
+        for (int j = 0; j < n_fpv; ++j) {  // parameter-major (n_fixed, n_vox): one row slice per fixed parameter
+            PNX_HIP(hipMemcpyAsync(tfx + j * nv + v0, fixed_pv + j * nv + v0, c * sizeof(T), hipMemcpyHostToDevice, s_in));
+            if constexpr (F32) {
+                int r = cvt(tfx + j * nv + v0, dfx + j * nv + v0, c, s_in);
+                if (r) return r;
+            }
+        }
+        wm[i] = v0 + c;
+        PNX_HIP(hipMemcpyAsync(&ctl->ready, &wm[i], sizeof(unsigned long long), hipMemcpyHostToDevice, s_in));
+        if (i == 0) {
+            PNX_HIP(hipEventRecord(ev_first, s_in));
+            first_recorded.store(1);
+        }
+        return PNX_OK;
+    };
+    ops.upload_sync = [&]() -> int {
+        PNX_HIP(hipStreamSynchronize(s_in));
+        return PNX_OK;
+    };
+    ops.first_piece_landed = [&]() { return first_recorded.load() && hipEventQuery(ev_first) == hipSuccess; };
+    ops.granule_ready = [&](int g) { return __atomic_load_n(&flags[g], __ATOMIC_ACQUIRE) != 0; };
+    ops.download = [&](int g, int ot) -> int {
         hipStream_t s_out = res.s[2 + ot];
-        auto body = [&]() -> int {
-            PNX_HIP(hipSetDevice(device));
-            StreamLaunch s2;
-            s2.phase = 2;
-            for (int g = ot; g < n_gran; g += n_out) {
-                int expect = 0;
-                if (claim[g].compare_exchange_strong(expect, 1)) {  // no helper got here yet: touch it ourselves
-                    touch(g);
-                    touched[g].store(1);
-                } else {
-                    while (!touched[g].load()) std::this_thread::yield();
-                }
-                for (;;) {
-                    if (__atomic_load_n(&flags[g], __ATOMIC_ACQUIRE)) break;
-                    if (failed.load()) return PNX_OK;
-                    if (kernel_done.load()) {  // the kernel raises every flag before it ends
-                        if (__atomic_load_n(&flags[g], __ATOMIC_ACQUIRE)) break;
-                        return set_error(PNX_ERR_HIP, "streamed curve fit: kernel ended without completing granule %d", g);
-                    }
-                    std::this_thread::yield();
-                }
-                t_flag[g] = now();
-                const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
-                if (pcov) {
-                    int r = curvefit_device(o, (int64_t)c, bd, nullptr, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, nullptr, dpcov + v0 * n * n,
-                                            dstat + v0, nullptr, dcost + v0, dev, s_out, &s2);
-                    if (r) return r;
-                }
-                if constexpr (F32) {
-                    int r = PNX_OK;
-                    for (int j = 0; j < n && !r; ++j) r = cvt(dpopt + j * nv + v0, tpopt + j * nv + v0, c, s_out);
-                    if (!r && pcov) r = cvt(dpcov + v0 * n * n, tpcov + v0 * n * n, c * n * n, s_out);
-                    if (!r && cost) r = cvt(dcost + v0, tcost + v0, c, s_out);
-                    if (r) return r;
-                }
-                for (int j = 0; j < n; ++j)
-                    PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, tpopt + j * nv + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
-                if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, tpcov + v0 * n * n, c * n * n * sizeof(T), hipMemcpyDeviceToHost, s_out));
-                if (status) PNX_HIP(hipMemcpyAsync(status + v0, dstat + v0, c, hipMemcpyDeviceToHost, s_out));
-                if (nfev) PNX_HIP(hipMemcpyAsync(nfev + v0, dnfev + v0, c * sizeof(int32_t), hipMemcpyDeviceToHost, s_out));
-                if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, tcost + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
-                PNX_HIP(hipStreamSynchronize(s_out));
-                t_out[g] = now();
-            }
-            return PNX_OK;
-        };
-        const int r = body();
-        if (r) fail(r);
-    });
-    const int touchers = env_int("PNX_HOST_TOUCHERS", 2, 0, 8);
-    for (int t = 0; t < touchers; ++t)
-        th.emplace_back([&]() {
-            for (int g = 0; g < n_gran && !failed.load(); ++g) {
-                int expect = 0;
-                if (claim[g].compare_exchange_strong(expect, 1)) {
-                    touch(g);
-                    touched[g].store(1);
-                }
-            }
-        });
-    hipError_t ke = hipStreamSynchronize(s_main);
-    const double t_kernel = now();
-    kernel_done.store(true);
-    for (auto &t : th) t.join();
-    if (ke != hipSuccess) return set_error(PNX_ERR_HIP, "streamed curve fit kernel: %s", hipGetErrorString(ke));
+        StreamLaunch s2;
+        s2.phase = 2;
+        const size_t v0 = (size_t)g << gshift, c = std::min(G, nv - v0);
+        if (pcov) {
+            int r = curvefit_device(o, (int64_t)c, bd, nullptr, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, nullptr, dpcov + v0 * n * n,
+                                    dstat + v0, nullptr, dcost + v0, dev, s_out, &s2);
+            if (r) return r;
+        }
+        if constexpr (F32) {
+            int r = PNX_OK;
+            for (int j = 0; j < n && !r; ++j) r = cvt(dpopt + j * nv + v0, tpopt + j * nv + v0, c, s_out);
+            if (!r && pcov) r = cvt(dpcov + v0 * n * n, tpcov + v0 * n * n, c * n * n, s_out);
+            if (!r && cost) r = cvt(dcost + v0, tcost + v0, c, s_out);
+            if (r) return r;
+        }
+        for (int j = 0; j < n; ++j)
+            PNX_HIP(hipMemcpyAsync(popt + j * nv + v0, tpopt + j * nv + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
+        if (pcov) PNX_HIP(hipMemcpyAsync(pcov + v0 * n * n, tpcov + v0 * n * n, c * n * n * sizeof(T), hipMemcpyDeviceToHost, s_out));
+        if (status) PNX_HIP(hipMemcpyAsync(status + v0, dstat + v0, c, hipMemcpyDeviceToHost, s_out));
+        if (nfev) PNX_HIP(hipMemcpyAsync(nfev + v0, dnfev + v0, c * sizeof(int32_t), hipMemcpyDeviceToHost, s_out));
+        if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, tcost + v0, c * sizeof(T), hipMemcpyDeviceToHost, s_out));
+        PNX_HIP(hipStreamSynchronize(s_out));
+        return PNX_OK;
+    };
+    ops.touch = touch;
+    ops.abort_kernel = [&]() { __atomic_store_n(abort_word, 1u, __ATOMIC_RELEASE); };
+    ops.kernel_state = [&]() -> int {
+        const hipError_t e = hipStreamQuery(s_main);
+        if (e == hipErrorNotReady) return 0;
+        return e == hipSuccess ? 1 : set_error(PNX_ERR_HIP, "streamed curve fit kernel: %s", hipGetErrorString(e));
+    };
+    ops.kernel_wait = [&]() -> int {
+        const hipError_t e = hipStreamSynchronize(s_main);
+        return e == hipSuccess ? PNX_OK : set_error(PNX_ERR_HIP, "streamed curve fit kernel: %s", hipGetErrorString(e));
+    };
+    // a watermark that has not moved this long after the launch will not move: the first piece lands after 0.7 ms (C3), a
+    // 512 Ki-voxel piece with per-voxel arrays after 3-4 ms
+    const double stall_ms = env_int("PNX_STREAM_STALL_MS", 50, 1, 60000);
+    bool stalled = false;
+    StreamedTimes times;
+    rc = run_streamed(n_in, n_gran, n_out, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), stall_ms, env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000),
+                      ops, &stalled, trace ? &times : nullptr, now);
+    (void)hipStreamSynchronize(s_in);  // nothing of this call is left on the kept streams
+    (void)hipEventDestroy(ev_first);
+    if (rc) return rc;
     StreamCtl head;
     PNX_HIP(hipMemcpy(&head, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost));
     if (trace) {
-        fprintf(stderr, "[pnx stream] %d granules of %zu voxels, %d upload pieces; launched %.2f kernel_done %.2f all_done %.2f ms%s\n",
-                n_gran, G, n_in, t_launched, t_kernel, now(), head.timed_out ? " TIMED OUT" : "");
-        for (int i = 0; i < n_in; i += std::max(1, n_in / 8)) fprintf(stderr, "[pnx stream] upload piece %d enqueued by %.2f ms\n", i, t_in[i]);
+        fprintf(stderr, "[pnx stream] %d granules of %zu voxels, %d upload pieces; launched %.2f kernel_done %.2f all_done %.2f ms%s%s\n",
+                n_gran, G, n_in, t_launched, times.t_kernel, now(), head.timed_out ? " TIMED OUT" : "", stalled ? " STALLED (gave up)" : "");
+        for (int i = 0; i < n_in; i += std::max(1, n_in / 8)) fprintf(stderr, "[pnx stream] upload piece %d enqueued by %.2f ms\n", i, times.t_in[i]);
         for (int g = 0; g < n_gran; g += std::max(1, n_gran / 8))
-            fprintf(stderr, "[pnx stream] granule %d complete at %.2f, downloaded by %.2f ms\n", g, t_flag[g], t_out[g]);
+            fprintf(stderr, "[pnx stream] granule %d complete at %.2f, downloaded by %.2f ms\n", g, times.t_flag[g], times.t_out[g]);
     }
-    if (failed.load()) return set_error(err_code, "%s", err_msg.c_str());
-    if (head.timed_out) return kStreamRetry;
+    if (stalled || head.timed_out) {
+        g_stream_cooldown[device].store(env_int("PNX_STREAM_COOLDOWN", 32, 0, 1 << 20));
+        return kStreamRetry;
+    }
     return PNX_OK;
 }
 
@@ -885,15 +711,21 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         // not for the kernels that need (almost) every register of a lane (pnx_curvefit_inst.hip launch_pv): the copies that
         // feed a streamed kernel have to fit beside it
         const bool tight = n >= 6 || (n >= 4 && o->t1_mode);
-        if (env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
+        bool cooling = false;
+        if (g_stream_cooldown[device].load() > 0) {  // a recent launch on this device stalled: the ring, without trying again
+            g_stream_cooldown[device].fetch_sub(1);
+            cooling = true;
+        }
+        if (!cooling && env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
             nv < ((size_t)1 << 31) && nv * per_vox <= max_bytes) {
             rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, pv ? p0 : nullptr, pv ? lo : nullptr, pv ? hi : nullptr, fxd,
                                       fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream);
             if (rc != kStreamRetry) return rc;
             static std::atomic<bool> warned(false);
             if (getenv("PNX_HOST_TRACE") || !warned.exchange(true))
-                fprintf(stderr, "[pnx stream] the streamed launch could not be used (no room for the staging slab, or its wait for the "
-                                "upload timed out); running the call through the chunk ring. PNX_HOST_STREAM=0 skips the attempt.\n");
+                fprintf(stderr, "[pnx stream] the streamed launch could not be used (no room for the staging slab, or its upload did not "
+                                "start within PNX_STREAM_STALL_MS); running the call through the chunk ring, and after a stall the next "
+                                "PNX_STREAM_COOLDOWN calls of this device too. PNX_HOST_STREAM=0 skips the attempt.\n");
         }
     }
 
@@ -1024,6 +856,7 @@ int pnx_release_staging(int device) {
     if (device < 0 || device >= 64) return set_error(PNX_ERR_INVALID, "device %d out of range", device);
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_sres_busy[device]) return set_error(PNX_ERR_INVALID, "device %d: a streamed call is using the staging set", device);
+    g_stream_cooldown[device].store(0);  // and the next host-array fit may try the streamed launch again
     int cur = 0;
     if (g_sres[device].slab || g_sres[device].pin || !g_sres[device].s.empty()) {
         (void)hipGetDevice(&cur);

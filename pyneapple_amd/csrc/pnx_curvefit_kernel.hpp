@@ -46,7 +46,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // order = data before watermark); `done[g]` counts the waves that will never touch granule g again.
 struct StreamCtl {
     unsigned long long ready;  // voxels [0, ready) are resident
-    unsigned int abort;        // host -> kernel: stop pulling voxels
+    unsigned int abort;        // (unused since round 4: the abort word is host_flags[n_granules], see CurvefitArgs)
     unsigned int timed_out;    // kernel -> host: a lane gave up waiting for the watermark
     unsigned int done[1];      // [n_granules]
 };
@@ -66,7 +66,10 @@ struct CurvefitArgs {
     // Streamed launch (host-pointer calls, pnx_api.hip `curvefit_streamed`): ONE persistent kernel runs while the volume is
     // still being uploaded and its results are already being downloaded.  ctl != null selects the STREAM instantiation.
     StreamCtl *ctl;             // device memory: upload watermark, abort word, per-granule wave counts
-    unsigned int *host_flags;   // pinned host memory: host_flags[g] = 1 once every wave has left granule g behind
+    unsigned int *host_flags;   // pinned host memory: host_flags[g] = 1 once every wave has left granule g behind; host_flags[n_granules]
+                                // is the ABORT word (host -> kernel: stop waiting for the watermark and leave).  It lives in host
+                                // memory so that the host can raise it with a plain store -- a copy into device memory would queue up
+                                // behind whatever stalls the upload stream, which is exactly when it is needed
     int granule_shift;          // granule = 1 << granule_shift voxels
     unsigned int stream_spins;  // watermark polls before a lane gives up (ctl->timed_out = 1)
     int phase;                  // 0: fit + covariance epilogue, 1: fit only, 2: covariance epilogue only
@@ -745,17 +748,18 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
             // visible).  Bounded: on abort or after stream_spins polls the lane leaves, so the grid always drains.
             if (idx >= ready_seen) {
                 bool got = false;
+                const unsigned int *abort_word = A.host_flags + ((A.n_vox + (1ll << A.granule_shift) - 1) >> A.granule_shift);
                 for (unsigned int spins = 0; spins < A.stream_spins; ++spins) {
                     ready_seen = __hip_atomic_load(&A.ctl->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (idx < ready_seen) {
                         got = true;
                         break;
                     }
-                    if (__hip_atomic_load(&A.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
                     __builtin_amdgcn_s_sleep(127);
                 }
                 if (!got) {
-                    if (!__hip_atomic_load(&A.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                    if (!__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
                         __hip_atomic_store(&A.ctl->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;  // leaves with state IDLE
                 }

@@ -79,7 +79,7 @@ def run(n_cases=100, seed=0, verbose=True):
             is_stream = "[pnx stream]" in text and "granules of" in text
             streamed += is_stream
             problems = []
-            if "timed out" in text or "TIMED OUT" in text:
+            if "timed out" in text or "TIMED OUT" in text or "STALLED" in text or "could not be used" in text:
                 problems.append("watermark time-out / fall-back")
             if is_stream != want_stream:
                 problems.append(f"streamed={is_stream}, expected {want_stream}")

@@ -526,15 +526,60 @@ def test_streamed_host_path_stalled_upload_falls_back(gpu, monkeypatch, capfd):
     monkeypatch.setenv("PNX_STREAM_SPINS", "1000")        # a few ms of polling
     monkeypatch.setenv("PNX_STREAM_TEST_DELAY_MS", "300")  # the upload starts long after that
     monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    monkeypatch.setenv("PNX_STREAM_STALL_MS", "5000")      # ... and the host's own watchdog stays out of it
     again = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
-    assert "timed out" in capfd.readouterr().err
+    err = capfd.readouterr().err
+    assert "TIMED OUT" in err and "chunk ring" in err
     for k in ("popt", "pcov", "status", "nfev", "cost"):
         np.testing.assert_array_equal(again[k], good[k], err_msg=k)
-    # the staging set kept between streamed calls can be dropped, and the next call builds a new one
+    # the staging set kept between streamed calls can be dropped (which also ends the ring-only period a stall starts), and the
+    # next call builds a new one
     gpu.release_staging(0)
     monkeypatch.delenv("PNX_STREAM_TEST_DELAY_MS")
     monkeypatch.delenv("PNX_STREAM_SPINS")
     third = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    assert "granules of" in capfd.readouterr().err  # streamed again
+    np.testing.assert_array_equal(third["popt"], good["popt"])
+
+
+def test_two_stalled_uploads_in_a_row_cost_one_stall(gpu, monkeypatch, capfd):
+    """A watermark that has not moved PNX_STREAM_STALL_MS after the launch will not move (the upload stream shares a hardware queue
+    with somebody's long kernel): the host raises the abort word -- a plain store into host memory the kernel polls -- and runs
+    the call through the chunk ring; it never waits for the kernel's own poll limit (2.4 s).  The condition is remembered: the
+    next calls of the device take the ring at once, until PNX_STREAM_COOLDOWN calls have passed or pnx_release_staging()."""
+    import time
+
+    from pyneapple_amd import synth
+
+    n_vox = 20000
+    b, y, _ = synth.make_numpy("bi_reduced", n_vox, 24, sigma=0.01, seed=3)
+    names, p0, lo, hi = synth.shared_arrays("bi_reduced")
+    monkeypatch.setenv("PNX_STREAM_GRANULE_SHIFT", "12")
+    monkeypatch.setenv("PNX_STREAM_IN_CHUNK", "4096")
+    gpu.release_staging(0)
+    good = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    monkeypatch.setenv("PNX_STREAM_TEST_DELAY_MS", "3000")  # the upload would start after 3 s: longer than the kernel's poll limit
+    monkeypatch.setenv("PNX_STREAM_STALL_MS", "50")
+    monkeypatch.setenv("PNX_HOST_TRACE", "1")
+    t = time.perf_counter()
+    first = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    t_first = time.perf_counter() - t
+    err = capfd.readouterr().err
+    assert "STALLED (gave up)" in err and "TIMED OUT" not in err
+    assert t_first < 1.0, t_first  # 50 ms of watching + the ring, not 2.4 s of polling or 3 s of stall
+    t = time.perf_counter()
+    second = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    t_second = time.perf_counter() - t
+    err = capfd.readouterr().err
+    assert "granules of" not in err  # no streamed launch was tried
+    assert t_second < 0.1, t_second
+    for r in (first, second):
+        for k in ("popt", "pcov", "status", "nfev", "cost"):
+            np.testing.assert_array_equal(r[k], good[k], err_msg=k)
+    monkeypatch.delenv("PNX_STREAM_TEST_DELAY_MS")
+    gpu.release_staging(0)  # ends the ring-only period
+    third = gpu.curvefit("bi_reduced", b, y, p0, lo, hi)
+    assert "granules of" in capfd.readouterr().err
     np.testing.assert_array_equal(third["popt"], good["popt"])
 
 
