@@ -214,8 +214,9 @@ int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg
  *     (log10 of the weighted geometric mean position -- the reference's own convention -- and the summed fraction);
  *     fractions renormalised over the ranges.
  *   spectrum (n_vox, n_bins) host|device; bins (n_bins,) host; cutoffs (n_cut, 2) host.
- *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks: the first max_peaks <= 16 are reported; a spectrum with more
- *     than 16 peaks gets NaN rows -- its fractions would have to be normalised over peaks the table cannot hold);
+ *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks: the first max_peaks <= 64 are reported; a spectrum with more
+ *     than 64 peaks -- 16 when it has a flat-topped rise, which takes SciPy's sequential scan on one lane -- gets NaN rows:
+ *     its fractions would have to be normalised over peaks the table cannot hold; a 250-bin spectrum has at most 124 maxima);
  *   d_values / f_values (n_vox, max_peaks) NaN padded; d_cut / f_cut (n_vox, n_cut <= 8).  Outputs host|device as `mem`.
  */
 int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectrum, const double *bins_host, double height,

@@ -229,7 +229,7 @@ def nnls_basis(b, bins, device=0):
     return out
 
 
-SPECTRUM_MAX_PEAKS = 16  # kMaxPeaks of csrc/pnx_spectrum.hip
+SPECTRUM_MAX_PEAKS = 64  # kMaxPeaks of csrc/pnx_spectrum.hip (one peak per lane of the wave that owns the spectrum)
 
 
 def spectrum_peaks(spectrum, bins, height=0.1, regularized=False, rel_height=0.5, max_peaks=8, cutoffs=None, device=0):
@@ -262,12 +262,16 @@ def spectrum_peaks(spectrum, bins, height=0.1, regularized=False, rel_height=0.5
                                              float(rel_height), int(max_peaks), ptr(out["n_peaks"]), ptr(out["d_values"]),
                                              ptr(out["f_values"]), n_cut, ptr(cut), ptr(out["d_cut"]), ptr(out["f_cut"]),
                                              MEM_DEVICE if tensor else MEM_HOST, int(device), stream))
-    if not tensor and n_vox and int(out["n_peaks"].max()) > SPECTRUM_MAX_PEAKS:
-        import warnings
+    if not tensor and n_vox:
+        # rows the device table could not hold: more than 64 peaks, or more than 16 in a spectrum with a flat-topped rise
+        over = out["n_peaks"] > SPECTRUM_MAX_PEAKS
+        if max_peaks:
+            over |= (out["n_peaks"] > 16) & np.isnan(out["d_values"][:, 0])
+        if over.any():
+            import warnings
 
-        k = int((out["n_peaks"] > SPECTRUM_MAX_PEAKS).sum())
-        warnings.warn(f"{k} spectra have more than {SPECTRUM_MAX_PEAKS} peaks (the device table's size): their peak and cutoff "
-                      f"rows are NaN; n_peaks holds the count", RuntimeWarning, stacklevel=2)
+            warnings.warn(f"{int(over.sum())} spectra have more than {SPECTRUM_MAX_PEAKS} peaks (the device table's size; 16 for a spectrum "
+                          f"with a flat-topped rise): their peak and cutoff rows are NaN; n_peaks holds the count", RuntimeWarning, stacklevel=2)
     return out
 
 

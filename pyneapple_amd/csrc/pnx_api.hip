@@ -415,8 +415,13 @@ struct StreamLease {
     }
     ~StreamLease() {
         if (kept) {
+            // the slab stays for the next call (a 2 GB hipMalloc / hipFree pair costs 2-3 ms of a 40 ms call) unless it is larger than
+            // PNX_STREAM_CACHE_MB or than a quarter of the HBM that would be free without it: on a device that is shared with a
+            // framework's caching allocator the library does not sit on memory others are short of
             const size_t cap = (size_t)env_int("PNX_STREAM_CACHE_MB", 8192, 0, 1 << 20) << 20;
-            if (r->slab_bytes > cap) {
+            size_t free_b = 0, total_b = 0;
+            const bool crowded = r->slab_bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && r->slab_bytes > (free_b + r->slab_bytes) / 4;
+            if (r->slab_bytes > cap || crowded) {
                 (void)hipFree(r->slab);
                 r->slab = nullptr;
                 r->slab_bytes = 0;
@@ -707,7 +712,19 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         // 128 Ki below (C3: 2^17 41.4-44 ms, 2^18 40.6-43.9 ms, 2^16 and 2^19 42-45 ms; profiles/stream_sweep.py)
         const int gshift = env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
         const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2 + (fpv ? o->n_fixed : 0) + (pv ? 3 * n : 0)) * (F32 ? 12 : 8);
-        const size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
+        size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
+        {   // never more than half of what is free now (plus the kept slab, which would be reused): a volume beyond that goes
+            // through the ring's three chunk slots instead of one huge hipMalloc that fails or starves the process
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                size_t kept = 0;
+                {
+                    std::lock_guard<std::mutex> lk(g_mu);
+                    if (!g_sres_busy[device]) kept = g_sres[device].slab_bytes;
+                }
+                max_bytes = std::min(max_bytes, free_b / 2 + kept);
+            }
+        }
         // not for the kernels that need (almost) every register of a lane (pnx_curvefit_inst.hip launch_pv): the copies that
         // feed a streamed kernel have to fit beside it
         const bool tight = n >= 6 || (n >= 4 && o->t1_mode);

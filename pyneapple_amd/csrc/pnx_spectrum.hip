@@ -29,7 +29,8 @@ namespace pnx {
 namespace {
 constexpr int kW = 64;
 constexpr int kMaxBins = 256;
-constexpr int kMaxPeaks = 16;  // per voxel, kept in registers
+constexpr int kMaxPeaks = 64;  // per voxel: peak k of the list lives in lane k of the wave that owns the spectrum
+constexpr int kSeqPeaks = 16;  // the one-lane path of flat-topped spectra keeps its list in registers: 16 (NaN rows beyond)
 constexpr int kMaxCut = 8;
 
 struct PeakArgs {
@@ -53,7 +54,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
     const int n = A.n_bins;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     // ---- scipy.signal._peak_finding_utils._local_maxima_1d + the height condition (hmin <= x[peak])
-    int pk[kMaxPeaks];
+    int pk[kSeqPeaks];
     int m = 0, total = 0;
     {
         int i = 1;
@@ -65,9 +66,9 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
                 if (x[ia] < x[i]) {
                     const int mid = (i + ia - 1) / 2;
                     if (A.height <= x[mid]) {
-                        if (m < kMaxPeaks) {
+                        if (m < kSeqPeaks) {
 #pragma unroll
-                            for (int k = 0; k < kMaxPeaks; ++k)
+                            for (int k = 0; k < kSeqPeaks; ++k)
                                 if (k == m) pk[k] = mid;  // static indexing: the list stays in registers
                             ++m;
                         }
@@ -79,7 +80,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
             ++i;
         }
     }
-    if (total > kMaxPeaks) {  // more peaks than the table holds: NaN everywhere rather than fractions normalised over a part
+    if (total > kSeqPeaks) {  // more peaks than the table holds: NaN everywhere rather than fractions normalised over a part
         if (A.n_peaks) A.n_peaks[vox] = total;
         if (A.d_values)
             for (int k = 0; k < A.max_peaks; ++k) A.d_values[(size_t)vox * A.max_peaks + k] = A.f_values[(size_t)vox * A.max_peaks + k] = nan;
@@ -88,10 +89,10 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
         return;
     }
     // ---- fractions: raw heights, or the Gaussian area from the width at rel_height of the prominence
-    double fv[kMaxPeaks], dv[kMaxPeaks];
+    double fv[kSeqPeaks], dv[kSeqPeaks];
     double fsum = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxPeaks; ++k) {
+    for (int k = 0; k < kSeqPeaks; ++k) {
         fv[k] = nan;
         dv[k] = nan;
         if (k < m) {
@@ -139,7 +140,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
     }
     if (fsum > 0) {
 #pragma unroll
-        for (int k = 0; k < kMaxPeaks; ++k)
+        for (int k = 0; k < kSeqPeaks; ++k)
             if (k < m) fv[k] = fv[k] / fsum;
     }
     if (A.n_peaks) A.n_peaks[vox] = total;
@@ -147,7 +148,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
         for (int k = 0; k < A.max_peaks; ++k) {
             double d = nan, f = nan;
 #pragma unroll
-            for (int j = 0; j < kMaxPeaks; ++j)
+            for (int j = 0; j < kSeqPeaks; ++j)
                 if (j == k) {
                     d = dv[j];
                     f = fv[j];
@@ -170,7 +171,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
                 int cnt = 0;
                 double hs = 0, d1 = 0, f1 = 0;
 #pragma unroll
-                for (int k = 0; k < kMaxPeaks; ++k)
+                for (int k = 0; k < kSeqPeaks; ++k)
                     if (k < m && dv[k] >= lo && dv[k] <= hi) {
                         ++cnt;
                         hs += fv[k];
@@ -184,7 +185,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
                     // geometric_mean_peak (spectrum.py:106-139): log10(prod(pos ** (h / sum h))), sum h
                     double prod = 1.0;
 #pragma unroll
-                    for (int k = 0; k < kMaxPeaks; ++k)
+                    for (int k = 0; k < kSeqPeaks; ++k)
                         if (k < m && dv[k] >= lo && dv[k] <= hi) prod *= pow(dv[k], fv[k] / hs);
                     dc[c] = log10(prod);
                     fc[c] = hs;
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
         }
         Mask4 peaks = ballot4(pk);
         const int total = __popcll(peaks.m[0]) + __popcll(peaks.m[1]) + __popcll(peaks.m[2]) + __popcll(peaks.m[3]);
-        if (total > kMaxPeaks) {  // more peaks than the table (one per lane 0..15) holds: NaN, never a partial normalisation
+        if (total > kMaxPeaks) {  // more peaks than the table (one per lane) holds: NaN, never a partial normalisation
             if (A.n_peaks && lane == 0) A.n_peaks[vox] = total;
             if (A.d_values && lane < A.max_peaks) A.d_values[(size_t)vox * A.max_peaks + lane] = A.f_values[(size_t)vox * A.max_peaks + lane] = nan;
             if (A.d_cut && lane < A.n_cut) A.d_cut[(size_t)vox * A.n_cut + lane] = A.f_cut[(size_t)vox * A.n_cut + lane] = nan;

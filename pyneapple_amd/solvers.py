@@ -231,9 +231,33 @@ class HipCurveFitSolver(CurveFitBase):
             p0, lo, hi = tile(p0), tile(lo), tile(hi)
         return np.asarray(p0, float), np.asarray(lo, float), np.asarray(hi, float), per_voxel
 
+    # ------------------------------------------------------------------ device memory kept between fits
+    def close(self) -> None:
+        """Give back what host-array fits keep on the device between calls: the staging slab of a streamed fit (the size of the
+        volume: 2.1 GB for 256 x 256 x 64 x 32), its pinned block and its streams (`pnx_release_staging`).  The next fit builds
+        them again (2-3 ms).  Called when the solver is garbage collected; safe to call twice."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        try:
+            for k in range(max(1, int(getattr(self, "n_gpus", 1)))):
+                api.release_staging(int(self.device) + k)
+        except Exception:  # another solver's call is using the set, the device is gone, the interpreter is shutting down ...
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
     # ------------------------------------------------------------------ fit (curvefit.py:91-159)
     def fit(self, xdata: np.ndarray, ydata: np.ndarray, p0=None, bounds=None,
             pixel_fixed_params: dict[str, np.ndarray] | None = None, **fit_kwargs) -> "HipCurveFitSolver":
+        self._closed = False  # from here on there may be something to give back
         # **fit_kwargs: accepted and unused, exactly like the reference (curvefit.py:91-159 never reads them)
         self._reset_state()
         xdata = np.asarray(xdata)

@@ -30,9 +30,10 @@ def find_spectrum_peaks(spectrum, bins, height: float = 0.1, regularized: bool =
         warnings.simplefilter("ignore", RuntimeWarning)
         d, f, n = find_spectrum_peaks_batch(np.asarray(spectrum, float)[None, :], bins, height, regularized,
                                             max_peaks=api.SPECTRUM_MAX_PEAKS)
-    if int(n[0]) > api.SPECTRUM_MAX_PEAKS:
+    if int(n[0]) > api.SPECTRUM_MAX_PEAKS or (int(n[0]) > 0 and np.isnan(d[0, 0])):
         raise ValueError(f"the spectrum has {int(n[0])} peaks at height {height}; the device kernel keeps at most "
-                         f"{api.SPECTRUM_MAX_PEAKS} per voxel (raise `height`, or regularise the fit)")
+                         f"{api.SPECTRUM_MAX_PEAKS} per voxel (16 for a spectrum with a flat-topped rise): raise `height`, or "
+                         f"regularise the fit")
     k = int(n[0])
     return d[0, :k].copy(), f[0, :k].copy()
 

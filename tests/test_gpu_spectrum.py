@@ -107,26 +107,37 @@ def test_parameter_maps_on_device(gpu):
 
 
 def test_more_peaks_than_the_table_holds_is_flagged_not_truncated(gpu):
-    """A spectrum with more than 16 local maxima above `height` (an unregularised, noisy fit at a low threshold): the rows of
-    that voxel are NaN and n_peaks reports the count -- never fractions normalised over the first 16 peaks only."""
+    """The device table holds 64 peaks per spectrum (round 3: 16).  A noisy unregularised spectrum at a low threshold with 20 or
+    24 maxima is reported in full, as the reference's find_spectrum_peaks does; one with more than 64 (a 250-bin spectrum has at
+    most 124 maxima) gets NaN rows and its count in n_peaks -- never fractions normalised over a part of its peaks."""
     import warnings
 
     from pyneapple_amd import spectrum
 
     bins = np.logspace(-3, 0, 250)
-    x = np.zeros((3, 250))
+    x = np.zeros((4, 250))
     x[0, 10::12] = 1.0  # 20 isolated peaks
     x[1, [30, 90]] = (1.0, 3.0)
     x[2, 5:245:10] = np.linspace(1, 2, 24)  # 24 peaks
+    x[3, 2:212:3] = 1.0  # 70 peaks
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        d, f, n = spectrum.find_spectrum_peaks_batch(x, bins, height=0.1, max_peaks=16)
+        d, f, n = spectrum.find_spectrum_peaks_batch(x, bins, height=0.1, max_peaks=32)
         dc, fc = spectrum.apply_cutoffs_batch(x, bins, [(1e-3, 3e-2), (3e-2, 1.0)], height=0.1)
-    assert [int(v) for v in n] == [20, 2, 24] and any("more than 16 peaks" in str(m.message) for m in w)
-    assert np.isnan(d[0]).all() and np.isnan(f[0]).all() and np.isnan(d[2]).all() and np.isnan(dc[0]).all() and np.isnan(fc[2]).all()
+    assert [int(v) for v in n] == [20, 2, 24, 70] and any("more than 64 peaks" in str(m.message) for m in w)
+    np.testing.assert_allclose(d[0, :20], bins[10::12])
+    np.testing.assert_allclose(f[0, :20], 1.0 / 20)
+    assert np.isnan(d[0, 20:]).all()
+    np.testing.assert_allclose(d[2, :24], bins[5:245:10])
+    np.testing.assert_allclose(f[2, :24], np.linspace(1, 2, 24) / np.linspace(1, 2, 24).sum())
     np.testing.assert_allclose(f[1, :2], [0.25, 0.75])
-    assert np.isfinite(fc[1]).any()
-    with pytest.raises(ValueError, match="20 peaks"):
-        spectrum.find_spectrum_peaks(x[0], bins, height=0.1)
+    assert np.isnan(d[3]).all() and np.isnan(f[3]).all() and np.isnan(dc[3]).all() and np.isnan(fc[3]).all()
+    assert np.isfinite(fc[0]).any() and np.isfinite(fc[1]).any() and np.isfinite(fc[2]).any()
+    np.testing.assert_allclose(fc[0].sum(), 1.0)
+    with pytest.raises(ValueError, match="70 peaks"):
+        spectrum.find_spectrum_peaks(x[3], bins, height=0.1)
+    dd, ff = spectrum.find_spectrum_peaks(x[0], bins, height=0.1)  # the reference returns every peak; so does this
+    assert dd.shape == (20,)
+    np.testing.assert_allclose(ff, 1.0 / 20)
     dd, ff = spectrum.find_spectrum_peaks(x[1], bins, height=0.1)
     np.testing.assert_allclose(ff, [0.25, 0.75])
