@@ -159,10 +159,10 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  * The plan picks the kernel; all of them walk the Lawson-Hanson path of scipy.optimize.nnls (same iteration counts):
  *   - reg = one of the reference's banded matrices (model_functions/nnls.py:46-85, orders 1-3) and n_meas <= 32 (every
  *     configuration the reference ships): basis resident in LDS, residual-form dual (csrc/pnx_nnls_blk.hip);
- *   - no regulariser / an all-zero one (reg_order = 0, the reference default) and n_meas <= 64: QR form (pnx_nnls_qr.hip);
- *     with n_meas > 64 the plan is REFUSED (PNX_ERR_UNSUPPORTED) unless the basis is well conditioned
- *     (cond(basis)^2 < ~1e10, n_meas >= n_bins): the normal-equation kernel would pick other columns than SciPy on a
- *     rank-deficient basis, and this library never changes the algorithm silently;
+ *   - no regulariser / an all-zero one (reg_order = 0, the reference default): QR form (pnx_nnls_qr.hip) -- Q and R in LDS
+ *     up to 64 measurements, in a per-wave global slab from 65 to 128 (264 KB per resident wave, allocated on the first
+ *     solve of such a plan); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
+ *     this library never changes the algorithm silently;
  *   - anything else (dense regularisers, 33..128 measurements): Gram form (pnx_nnls.hip).
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;

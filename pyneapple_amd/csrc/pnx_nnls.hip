@@ -799,40 +799,10 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
         // condition number of ~1e16 -- those fits go through the QR-based kernel
         bool zero = true;
         for (size_t i = 0; i < (size_t)n_reg * n_bins && zero; ++i) zero = reg[i] == 0.0;
-        P->qr = zero && n_meas <= 64 && !getenv("PNX_NNLS_NO_QR");
-        // never a silently different algorithm: the QR-form kernel keeps one measurement per lane (<= 64 of them).  Beyond
-        // that the Gram form is only an answer when the basis is well conditioned (it works with cond(A)^2): a pivoted
-        // look at chol(B^T B) on the host decides, once per plan
-        if (zero && n_meas > 64 && !getenv("PNX_NNLS_NO_QR")) {
-            std::vector<double> Gh((size_t)n_bins * n_bins, 0.0);
-            for (int i = 0; i < n_bins; ++i)
-                for (int j = 0; j <= i; ++j) {
-                    double acc = 0;
-                    for (int k = 0; k < n_meas; ++k) acc += basis[(size_t)k * n_bins + i] * basis[(size_t)k * n_bins + j];
-                    Gh[(size_t)i * n_bins + j] = acc;
-                }
-            double gmax = 0, pmin = INFINITY;
-            for (int i = 0; i < n_bins; ++i) gmax = std::fmax(gmax, Gh[(size_t)i * n_bins + i]);
-            bool ok = n_meas >= n_bins && gmax > 0;
-            for (int i = 0; i < n_bins && ok; ++i) {  // plain Cholesky, in place
-                for (int j = 0; j <= i; ++j) {
-                    double acc = Gh[(size_t)i * n_bins + j];
-                    for (int k = 0; k < j; ++k) acc -= Gh[(size_t)i * n_bins + k] * Gh[(size_t)j * n_bins + k];
-                    if (j < i)
-                        Gh[(size_t)i * n_bins + j] = acc / Gh[(size_t)j * n_bins + j];
-                    else {
-                        pmin = std::fmin(pmin, acc);
-                        ok = acc > 1e-10 * gmax;  // cond(A)^2 beyond ~1e10: the Gram form has no digits to spare
-                        Gh[(size_t)i * n_bins + i] = ok ? std::sqrt(acc) : 1.0;
-                    }
-                }
-            }
-            if (!ok)
-                return set_error(PNX_ERR_UNSUPPORTED,
-                                 "NNLS without a regulariser (reg_order = 0 or mu = 0) and n_meas = %d > 64: the basis is rank "
-                                 "deficient or too ill conditioned for the normal-equation kernel (smallest Cholesky pivot %.3g of "
-                                 "%.3g); use a regulariser or at most 64 measurements", n_meas, pmin, gmax);
-        }
+        // up to 64 measurements with Q and R in LDS, 65 .. 128 with both in a per-wave global slab (pnx_nnls_qr.hip): never a
+        // silently different algorithm, and since round 4 no refusal either -- the reference's default has no limit on the
+        // number of b-values (nnls_solver.py:37, 88-127)
+        P->qr = zero && !getenv("PNX_NNLS_NO_QR");
     }
     const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)(kNnlsMaxBins + 1) * kNnlsMaxBins;  // one row more: the block kernel gathers column 256 (its padding bin) of a row
     for (size_t i = 0; i < nb; ++i)
@@ -891,6 +861,7 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
     if (P->Mblk) (void)hipFree(P->Mblk);
+    if (P->qr_slab) (void)hipFree(P->qr_slab);
     if (P->blk_bail) (void)hipFree(P->blk_bail);
     if (P->aty) (void)hipFree(P->aty);
     if (P->queue) (void)hipFree(P->queue);

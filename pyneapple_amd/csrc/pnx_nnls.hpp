@@ -25,7 +25,9 @@ struct NnlsPlanData {
     double rc[5] = {0, 0, 0, 0, 0};  // banded Toeplitz regulariser (orders 1-3 of the reference): reg[i][j] = rc[j - i + 2]
     int rhb = 0;              // its half bandwidth, 0 = general regulariser
     bool mfma_ok = false;     // the MFMA Gram step can run for this plan (n_meas <= 64)
-    bool qr = false;          // no (or an all-zero) regulariser and <= 64 measurements: QR-based kernel (pnx_nnls_qr.hip)
+    bool qr = false;          // no (or an all-zero) regulariser: QR-based kernels (pnx_nnls_qr.hip; Q and R in LDS up to 64 measurements, in a global slab beyond)
+    double *qr_slab = nullptr;  // Q / R of the 65 .. 128 measurement kernel, per resident wave
+    int qr_slab_groups = 0;
     bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
     int blk_groups = 0;       // its persistent workgroups (16 waves each)

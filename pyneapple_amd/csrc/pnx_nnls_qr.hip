@@ -371,6 +371,374 @@ template <int MP> int launch_qr(NnlsPlanData *P, const QrArgs &a, hipStream_t st
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "nnls_qr launch: %s", hipGetErrorString(e));
     return PNX_OK;
 }
+
+// ---- 65 .. 128 measurements (round 4) ---------------------------------------------------------------------------
+// The reference's default regulariser (reg_order = 0) has no limit on the number of b-values (nnls_solver.py:37, 88-127).  With
+// more than 64 of them a measurement-indexed vector takes two register slots per lane, and Q and R (128 x 129 doubles each) no
+// longer fit the LDS of a CU: they live in a per-wave slab in global memory (zero pages until touched; the passive set of an
+// unregularised fit is small -- 5.5 bins on average on the reference workload -- so the rows in use stay in L2).  Same
+// algorithm, same decisions and the same order of every floating-point sum as the kernel above wherever a sum is not a wave
+// reduction; (Q^T v)_i is a wave reduction here (the rows of Q are read coalesced) where the LDS kernel walks a row per lane,
+// so the two differ by rounding in l = Q^T v -- as either does from SciPy's Householder form.
+constexpr int kQS = 2;             // register slots of a vector by measurement / by position
+constexpr int kQM = kQS * kW;      // 128
+constexpr int kQST = kQM + 1;
+constexpr size_t kQrSlab = 2 * (size_t)kQM * kQST;  // doubles per wave: Qt | Rc
+
+__device__ __forceinline__ double rlk(const double (&a)[kQS], int k) { return (k >> 6) ? rl(a[1], k & 63) : rl(a[0], k & 63); }
+__device__ __forceinline__ int rlk_i(const int (&a)[kQS], int k) {
+    return (k >> 6) ? __builtin_amdgcn_readlane(a[1], k & 63) : __builtin_amdgcn_readlane(a[0], k & 63);
+}
+
+struct QrBigArgs {
+    QrArgs a;
+    double *slab;  // kQrSlab doubles per workgroup
+};
+
+__global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
+    const QrArgs &A = BA.a;
+    __shared__ double abuf[kQM], lbuf[kQM];
+    double *Qt = BA.slab + (size_t)blockIdx.x * kQrSlab;  // [kQM][kQST]  Qt[i][m]: column i of Q
+    double *Rc = Qt + (size_t)kQM * kQST;                 // [kQM][kQST]  Rc[k][i] = R[i][k]
+    const int lane = threadIdx.x;
+    const int n = A.n_bins, nm = A.n_meas;
+    auto sync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+
+    for (long long vox = blockIdx.x; vox < A.n_vox; vox += gridDim.x) {
+        double yv[kQS], res[kQS], xpos[kQS], z[kQS], qtb[kQS], diag[kQS];
+        int pidx[kQS];
+        double y2 = 0;
+        bool fin = true;
+#pragma unroll
+        for (int s = 0; s < kQS; ++s) {
+            const int m = lane + kW * s;
+            yv[s] = m < nm ? A.y[(size_t)vox * nm + m] : 0.0;
+            fin = fin && isfinite(yv[s]);
+            y2 = fma(yv[s], yv[s], y2);
+            res[s] = yv[s];
+            xpos[s] = z[s] = qtb[s] = 0;
+            diag[s] = 1;
+            pidx[s] = 0;
+        }
+        const bool finite = __all(fin ? 1 : 0) != 0;
+        const double yn2 = wave_sum(y2);
+        bool inP[kSlots] = {false, false, false, false};
+        int p = 0, iteration = 0, status = finite ? 1 : -2;
+        int guard = 0;
+        const int guard_max = 8 * A.max_iter + 4 * n + 64;
+        while (status == 1 && p < n && p < nm) {
+            if (++guard > guard_max) {
+                status = 0;
+                break;
+            }
+            // ---- dual w = B^T res on the zero set
+            double w[kSlots] = {0, 0, 0, 0};
+#pragma unroll 4
+            for (int k = 0; k < nm; ++k) {
+                const double rk = rlk(res, k);
+                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
+                const double2 b0 = *reinterpret_cast<const double2 *>(br);
+                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
+                w[0] = fma(b0.x, rk, w[0]);
+                w[1] = fma(b0.y, rk, w[1]);
+                w[2] = fma(b1.x, rk, w[2]);
+                w[3] = fma(b1.y, rk, w[3]);
+            }
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
+
+            bool accepted = false;
+            int jmax = 0;
+            double lam = 0, qn = 0;
+            double l[kQS] = {0, 0}, v[kQS] = {0, 0};
+            for (;;) {
+                if (++guard > guard_max) break;
+                double best = fmax(fmax(w[0], w[1]), fmax(w[2], w[3]));
+                best = wave_max(best);
+                if (uni(!(best > 0))) break;  // KKT satisfied
+                int bj = kNone;
+#pragma unroll
+                for (int s = kSlots - 1; s >= 0; --s)
+                    if (w[s] == best) bj = binof(lane, s);
+                jmax = uni_i(wave_min_i(bj));
+                if (jmax >= n) break;
+                // ---- candidate column a (by measurement), orthogonalised against Q twice
+#pragma unroll
+                for (int s = 0; s < kQS; ++s) {
+                    const int m = lane + kW * s;
+                    v[s] = m < nm ? A.Bp[(size_t)m * kNnlsMaxBins + jmax] : 0.0;
+                    l[s] = 0;
+                }
+                for (int pass = 0; pass < 2; ++pass) {
+                    sync();
+                    for (int i = 0; i < p; ++i) {  // (Q^T v)_i: a coalesced row of Q against v, summed over the wave
+                        double part = 0;
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) part = fma(Qt[(size_t)i * kQST + lane + kW * s], v[s], part);  // measurements >= nm hold zeros
+                        const double li = wave_sum(part);
+                        if (lane == 0) lbuf[i] = li;
+                    }
+                    sync();
+#pragma unroll
+                    for (int s = 0; s < kQS; ++s) {
+                        const int i = lane + kW * s;
+                        if (i < p) l[s] += lbuf[i];
+                    }
+                    for (int i = 0; i < p; ++i) {
+                        const double li = lbuf[i];
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) v[s] = fma(-Qt[(size_t)i * kQST + lane + kW * s], li, v[s]);
+                    }
+                }
+                double l2 = 0, v2 = 0, vres = 0;
+#pragma unroll
+                for (int s = 0; s < kQS; ++s) {
+                    if (lane + kW * s < p) l2 = fma(l[s], l[s], l2);
+                    v2 = fma(v[s], v[s], v2);
+                    vres = fma(v[s], res[s], vres);
+                }
+                const double ll = wave_sum(l2);
+                const double vv = wave_sum(v2);
+                lam = sqrt(vv);
+                const double un = sqrt(ll);
+                const double vr = wave_sum(vres);  // v is orthogonal to Q: v^T b = v^T res
+                bool ok = uni(((un + lam * 0.01) - un) > 0);  // Lawson-Hanson linear-independence test
+                if (ok) {
+                    qn = vr / lam;
+                    ok = uni((qn / lam) > 0);  // ztest
+                }
+                if (ok) {
+                    accepted = true;
+                    break;
+                }
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (binof(lane, s) == jmax) w[s] = 0.0;  // reject: look for the next largest
+            }
+            if (!accepted) break;
+
+            // ---- column jmax enters at position p
+            {
+                sync();
+#pragma unroll
+                for (int s = 0; s < kQS; ++s) {
+                    const int k = lane + kW * s;
+                    const double qv = v[s] / lam;
+                    Qt[(size_t)p * kQST + k] = qv;  // measurements >= nm: v = 0
+                    Rc[(size_t)p * kQST + k] = k < p ? l[s] : (k == p ? lam : 0.0);
+                    res[s] = fma(-qv, qn, res[s]);
+                    if (k == p) {
+                        qtb[s] = qn;
+                        diag[s] = lam;
+                        pidx[s] = jmax;
+                        xpos[s] = 0;
+                    }
+                }
+                sync();
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (binof(lane, s) == jmax) inP[s] = true;
+                p += 1;
+            }
+
+            // ---- inner loop
+            for (;;) {
+                if (status != 1) break;
+                // z = R^{-1} Q^T b: back substitution over the columns of R
+                {
+                    double t[kQS] = {qtb[0], qtb[1]};
+                    for (int k = p - 1; k >= 0; --k) {
+                        const double zk = rlk(t, k) / rlk(diag, k);
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) {
+                            const int i = lane + kW * s;
+                            if (i == k) z[s] = zk;
+                            if (i < k) t[s] = fma(-Rc[(size_t)k * kQST + i], zk, t[s]);
+                        }
+                    }
+                }
+                iteration += 1;
+                if (iteration == A.max_iter) {
+                    status = 0;
+                    break;
+                }
+                bool viol[kQS];
+                bool anyv = false;
+#pragma unroll
+                for (int s = 0; s < kQS; ++s) {
+                    viol[s] = lane + kW * s < p && z[s] <= 0;
+                    anyv = anyv || viol[s];
+                }
+                if (!__any(anyv ? 1 : 0)) {
+#pragma unroll
+                    for (int s = 0; s < kQS; ++s)
+                        if (lane + kW * s < p) xpos[s] = z[s];
+                    break;
+                }
+                double T[kQS];
+                double tmin = INFINITY;
+#pragma unroll
+                for (int s = 0; s < kQS; ++s) {
+                    T[s] = viol[s] ? -xpos[s] / (z[s] - xpos[s]) : INFINITY;
+                    tmin = fmin(tmin, T[s]);
+                }
+                const double alpha = -wave_max(-tmin);
+                int cand = kNone;
+#pragma unroll
+                for (int s = kQS - 1; s >= 0; --s)
+                    if (viol[s] && T[s] == alpha) cand = lane + kW * s;
+                int jj = uni_i(wave_min_i(cand));  // first position with the minimum
+#pragma unroll
+                for (int s = 0; s < kQS; ++s)
+                    if (lane + kW * s < p) xpos[s] = xpos[s] + alpha * (z[s] - xpos[s]);
+                for (;;) {
+                    if (++guard > guard_max || jj >= p) {
+                        status = 0;
+                        break;
+                    }
+                    // ---- position jj leaves: delete column jj of R, restore the triangle with Givens rotations on the
+                    // rows (i, i + 1), i = jj .. p - 2, and rotate the columns of Q and the entries of Q^T b with them
+                    const int bin_out = rlk_i(pidx, jj);
+                    sync();
+                    for (int k = jj; k < p - 1; ++k) {
+                        double cv[kQS];
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) cv[s] = Rc[(size_t)(k + 1) * kQST + lane + kW * s];
+                        sync();
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) Rc[(size_t)k * kQST + lane + kW * s] = cv[s];
+                        sync();
+                    }
+                    for (int i = jj; i < p - 1; ++i) {
+                        sync();
+                        const double f = Rc[(size_t)i * kQST + i], g = Rc[(size_t)i * kQST + i + 1];  // uniform reads
+                        double c, sn, r;
+                        givens(f, g, c, sn, r);
+                        sync();
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) {
+                            const int k = lane + kW * s;
+                            if (k >= i && k < p - 1) {  // k = column of R
+                                const double a = Rc[(size_t)k * kQST + i], b = Rc[(size_t)k * kQST + i + 1];
+                                Rc[(size_t)k * kQST + i] = k == i ? r : c * a + sn * b;
+                                Rc[(size_t)k * kQST + i + 1] = k == i ? 0.0 : c * b - sn * a;
+                            }
+                            {  // columns i, i + 1 of Q (k = measurement)
+                                const double a = Qt[(size_t)i * kQST + k], b = Qt[(size_t)(i + 1) * kQST + k];
+                                Qt[(size_t)i * kQST + k] = c * a + sn * b;
+                                Qt[(size_t)(i + 1) * kQST + k] = c * b - sn * a;
+                            }
+                        }
+                        const double t1 = rlk(qtb, i), t2 = rlk(qtb, i + 1);
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) {
+                            const int k = lane + kW * s;
+                            if (k == i) {
+                                qtb[s] = c * t1 + sn * t2;
+                                diag[s] = r;
+                            }
+                            if (k == i + 1) qtb[s] = c * t2 - sn * t1;
+                        }
+                    }
+                    sync();
+                    // the last (rotated) direction leaves the basis: its share of b goes back into the residual
+                    {
+                        const double ql = rlk(qtb, p - 1);
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) res[s] = fma(Qt[(size_t)(p - 1) * kQST + lane + kW * s], ql, res[s]);
+                    }
+                    {  // positions above jj move down by one
+                        double xs[kQS];
+                        int ps[kQS];
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) {
+                            xs[s] = __shfl_down(xpos[s], 1);
+                            ps[s] = __shfl_down(pidx[s], 1);
+                            if (lane == kW - 1 && s + 1 < kQS) {
+                                xs[s] = rl(xpos[s + 1 < kQS ? s + 1 : s], 0);
+                                ps[s] = __builtin_amdgcn_readlane(pidx[s + 1 < kQS ? s + 1 : s], 0);
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < kQS; ++s) {
+                            const int k = lane + kW * s;
+                            if (k >= jj && k < p - 1) {
+                                xpos[s] = xs[s];
+                                pidx[s] = ps[s];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s)
+                        if (binof(lane, s) == bin_out) inP[s] = false;
+                    p -= 1;
+                    // round-off clean-up: any remaining x <= 0 leaves too (first position first)
+                    int bc = kNone;
+#pragma unroll
+                    for (int s = kQS - 1; s >= 0; --s)
+                        if (lane + kW * s < p && xpos[s] <= 0) bc = lane + kW * s;
+                    const int bad = uni_i(wave_min_i(bc));
+                    if (bad == kNone) break;
+                    jj = bad;
+                }
+            }
+        }
+        // ---- outputs
+        double xb[kSlots] = {0, 0, 0, 0};
+        if (status == 1) {
+            for (int i = 0; i < p; ++i) {
+                const int b = rlk_i(pidx, i);
+                const double xv = rlk(xpos, i);
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s)
+                    if (binof(lane, s) == b) xb[s] = xv;
+            }
+        }
+        double *cv = A.coeff + (size_t)vox * n;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int j = binof(lane, s);
+            if (j < n) cv[j] = xb[s];
+        }
+        double r2p = 0;
+#pragma unroll
+        for (int s = 0; s < kQS; ++s) r2p = fma(res[s], res[s], r2p);
+        const double r2 = wave_sum(r2p);
+        const double rn = sqrt(status == 1 ? r2 : yn2);  // failure: zeros, ||y|| (nnls_solver.py:205-210)
+        if (lane == 0) {
+            A.rnorm[vox] = rn;
+            if (A.status) A.status[vox] = (int8_t)status;
+            if (A.iters) A.iters[vox] = iteration;
+        }
+        sync();  // the next voxel's first append overwrites row 0 of the slab
+    }
+}
+
+int launch_qr_big(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_qr_big_kernel, kW, 0) != hipSuccess || occ < 1)
+        return set_error(PNX_ERR_HIP, "nnls_qr_big_kernel does not fit on a CU");
+    if (occ > 8) occ = 8;  // 264 KB of Q / R per wave: 8 waves per CU are 540 MB of slab, of which a fit touches the rows of its passive set
+    long long grid = (long long)occ * P->cus;
+    if (!P->qr_slab || P->qr_slab_groups < grid) {
+        if (P->qr_slab) (void)hipFree(P->qr_slab);
+        P->qr_slab = nullptr;
+        if (hipMalloc(&P->qr_slab, (size_t)grid * kQrSlab * sizeof(double)) != hipSuccess)
+            return set_error(PNX_ERR_NOMEM, "hipMalloc of the Q / R slab (%zu bytes) failed", (size_t)grid * kQrSlab * sizeof(double));
+        // rows / columns >= p are never read before they are written, except the measurements >= n_meas of a row of Q, which the
+        // append writes as zeros: no initialisation needed
+        P->qr_slab_groups = (int)grid;
+    }
+    if (grid > a.n_vox) grid = a.n_vox;
+    QrBigArgs ba;
+    ba.a = a;
+    ba.slab = P->qr_slab;
+    hipLaunchKernelGGL(nnls_qr_big_kernel, dim3((unsigned)grid), dim3(kW), 0, stream, ba);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(PNX_ERR_HIP, "nnls_qr_big launch: %s", hipGetErrorString(e));
+    return PNX_OK;
+}
 }  // namespace
 
 int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
@@ -387,6 +755,7 @@ int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int 
     a.n_meas = P->n_meas;
     a.n_bins = P->n_bins;
     a.max_iter = max_iter;
+    if (P->n_meas > 64) return launch_qr_big(P, a, stream);
     return P->n_meas <= 32 ? launch_qr<32>(P, a, stream) : launch_qr<64>(P, a, stream);
 }
 

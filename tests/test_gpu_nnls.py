@@ -90,21 +90,50 @@ def test_edge_shapes_and_failures(gpu, oracle):
         gpu.nnls(np.ones((4, 300)), None, np.ones((1, 4)))  # > 256 bins: refused, not silently wrong
 
 
-def test_unregularised_beyond_64_measurements_is_refused_not_switched(gpu):
-    """reg_order = 0 (the reference default, nnls_solver.py:37) with 65..128 measurements: the QR-form kernel keeps one
-    measurement per lane, and the Gram-form kernel selects other columns than SciPy on such ill conditioned bases
-    (DESIGN section 3): the plan is refused with PNX_ERR_UNSUPPORTED instead of quietly taking the other algorithm.
-    A well conditioned overdetermined basis (cond^2 far from 1 / eps) is what the Gram form is exact for, and stays."""
+@pytest.mark.parametrize("n_b,n_bins", [(96, 250), (65, 250), (128, 256), (100, 60)])
+def test_unregularised_beyond_64_measurements_matches_oracle(gpu, oracle, n_b, n_bins):
+    """reg_order = 0 (the reference default, nnls_solver.py:37) has no limit on the number of b-values.  Up to round 3 a plan
+    with 65..128 measurements was refused (the QR-form kernel keeps one measurement per lane, and the Gram-form kernel selects
+    other columns than SciPy on such ill conditioned bases); since round 4 a second QR-form kernel with two measurements per
+    lane and Q / R in a global slab follows the oracle's active-set path voxel by voxel -- same supports, same iteration
+    counts -- also where the passive set grows past 64 positions (the 100 x 60 basis is well conditioned: every bin enters)."""
     from pyneapple_amd import synth
-    from pyneapple_amd._lib import PnxError
-    b = np.linspace(0.0, 1200.0, 96)
-    bins = np.logspace(np.log10(0.0008), np.log10(0.5), 250)
+
+    bins = np.logspace(np.log10(0.0008), np.log10(0.5), n_bins)
+    b = np.linspace(0.0, 1200.0, n_b)
     basis = np.exp(-b[:, None] * bins[None, :])
-    with pytest.raises(PnxError) as e:
-        gpu.nnls(basis, np.zeros((250, 250)), np.ones((2, 96)), 250)
-    assert e.value.code == -2 and "64" in str(e.value)  # PNX_ERR_UNSUPPORTED
-    with pytest.raises(PnxError):
-        gpu.nnls(basis, None, np.ones((2, 96)), 250)
+    _, y, _ = synth.make_numpy("tri_reduced", 1500, n_b, sigma=0.01, seed=5, scale=1000.0)
+    for reg in (None, np.zeros((n_bins, n_bins))):
+        r = gpu.nnls(basis, reg, y, 400)
+        o = oracle.nnls(basis, reg, y, 400, n_threads=8)
+        np.testing.assert_array_equal(r["status"], o["status"])
+        ok = o["status"] == 1
+        assert ok.mean() > 0.9
+        same = ((r["coefficients"] > 0) == (o["coefficients"] > 0)).all(axis=1)
+        assert same[ok].mean() > 0.99, f"supports differ on {(~same[ok]).sum()} voxels"
+        assert (r["iters"] == o["iters"])[ok].mean() > 0.99
+        assert _scaled_err(r["coefficients"][ok & same], o["coefficients"][ok & same]).max() < 1e-6
+        np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9)  # the minimum itself: every voxel
+        assert (r["coefficients"] >= 0).all()
+
+
+def test_unregularised_passive_set_beyond_64_positions(gpu, oracle):
+    """A well conditioned tall basis (128 measurements, 100 widely spaced bins) and a signal that is a positive combination of
+    ALL columns: the passive set grows to 100 positions, i.e. into the second register slot of every position-indexed vector
+    of the two-slot kernel, and removals shift positions across the slot boundary."""
+    rng = np.random.default_rng(11)
+    n_b, n_bins = 128, 100
+    basis = np.abs(rng.standard_normal((n_b, n_bins))) + 0.1 * np.eye(n_b, n_bins)
+    x_true = rng.uniform(0.5, 2.0, (64, n_bins))
+    x_true[:, ::7] = 0.0
+    y = x_true @ basis.T + 1e-3 * rng.standard_normal((64, n_b))
+    r = gpu.nnls(basis, None, y, 1000)
+    o = oracle.nnls(basis, None, y, 1000, n_threads=8)
+    np.testing.assert_array_equal(r["status"], o["status"])
+    assert (o["status"] == 1).all() and ((o["coefficients"] > 0).sum(axis=1) > 64).all()
+    assert (r["iters"] == o["iters"]).mean() > 0.95
+    assert _scaled_err(r["coefficients"], o["coefficients"]).max() < 1e-8
+    np.testing.assert_allclose(r["residual"], o["residual"], rtol=1e-9)
 
 
 def test_builders_on_device(gpu):
