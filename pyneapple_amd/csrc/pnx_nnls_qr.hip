@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "pnx_internal.hpp"
 #include "pnx_nnls.hpp"
@@ -755,7 +756,13 @@ int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int 
     a.n_meas = P->n_meas;
     a.n_bins = P->n_bins;
     a.max_iter = max_iter;
-    if (P->n_meas > 64) return launch_qr_big(P, a, stream);
+    {
+        // 33 .. 64 measurements fit the LDS kernel (MP = 64: 67 KB, two waves per CU), but the slab kernel with its eight waves
+        // per CU is the faster one there too: 4.16 against 2.82 M voxels/s at 33 b-values, 2.85 against 1.72 M at 64
+        // (profiles/nnls_cliff_probe.py); PNX_NNLS_QR_SLAB_FROM=65 brings the LDS kernel back for comparison
+        static const int slab_from = getenv("PNX_NNLS_QR_SLAB_FROM") ? atoi(getenv("PNX_NNLS_QR_SLAB_FROM")) : 33;
+        if (P->n_meas >= slab_from || P->n_meas > 64) return launch_qr_big(P, a, stream);
+    }
     return P->n_meas <= 32 ? launch_qr<32>(P, a, stream) : launch_qr<64>(P, a, stream);
 }
 

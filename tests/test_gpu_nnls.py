@@ -90,7 +90,7 @@ def test_edge_shapes_and_failures(gpu, oracle):
         gpu.nnls(np.ones((4, 300)), None, np.ones((1, 4)))  # > 256 bins: refused, not silently wrong
 
 
-@pytest.mark.parametrize("n_b,n_bins", [(96, 250), (65, 250), (128, 256), (100, 60)])
+@pytest.mark.parametrize("n_b,n_bins", [(96, 250), (65, 250), (128, 256), (100, 60), (48, 250), (33, 120), (64, 250)])
 def test_unregularised_beyond_64_measurements_matches_oracle(gpu, oracle, n_b, n_bins):
     """reg_order = 0 (the reference default, nnls_solver.py:37) has no limit on the number of b-values.  Up to round 3 a plan
     with 65..128 measurements was refused (the QR-form kernel keeps one measurement per lane, and the Gram-form kernel selects
