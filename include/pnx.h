@@ -125,6 +125,19 @@ int pnx_model_n_params(int model);
 int pnx_release_staging(int device);
 
 /*
+ * Queue order of the calling thread's NEXT device-mode curve fit (PNX_MEM_DEVICE): `order_device` is a device array of n_vox
+ * int32, a permutation of 0 .. n_vox - 1; the kernel's k-th queue pull fits voxel order[k].  Results do not depend on the
+ * order (a voxel's arithmetic is its own); the run time does: a pass ends in the longest fits that were started last, so a
+ * caller that has a predictor of the evaluation counts -- the nfev map of a previous fit of the same volume (refits, the
+ * second step of the reference's SegmentedFitter) or of the previous level of the IDEAL pyramid (fitters/ideal.py:150-190)
+ * -- passes them longest first.  NULL (the default after every call) = ascending voxel index.
+ */
+int pnx_curvefit_queue_order(const int32_t *order_device);
+/* order (n int32, device) = the voxel indices by descending key (n doubles, device), equal keys in index order: the queue order
+ * for pnx_curvefit_queue_order from a predicted evaluation count per voxel.  Synchronises `stream`. */
+int pnx_queue_order_f64(const double *key_device, int64_t n, int32_t *order_device, int device, void *stream);
+
+/*
  * Batched bounded non-linear least squares, fp64, results matching SciPy 1.15 curve_fit(method="trf").
  * Replaces: CurveFitSolver._fit_data (curvefit.py:171-244) for all voxels at once.
  *

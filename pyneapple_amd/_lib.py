@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
     "pnx_resize2d_f64", "pnx_ideal_bounds_f64", "pnx_nnls_spectrum_peaks_f64", "pnx_nnls_solve_peaks_f64", "pnx_scatter_maps_f32",
     "pnx_mask_select_f64", "pnx_gather_rows_f64", "pnx_scatter_rows_t_f64", "pnx_row_ss_tot_f64", "pnx_upload", "pnx_download",
-    "pnx_label_sums_f64", "pnx_release_staging",
+    "pnx_label_sums_f64", "pnx_release_staging", "pnx_curvefit_queue_order", "pnx_queue_order_f64",
 ]
 
 
@@ -92,6 +92,10 @@ def load():
     vp, dp, fp = C.c_void_p, C.c_void_p, C.c_void_p
     lib.pnx_version.restype = C.c_int
     lib.pnx_release_staging.argtypes = [C.c_int]
+    lib.pnx_curvefit_queue_order.argtypes = [C.c_void_p]
+    lib.pnx_curvefit_queue_order.restype = C.c_int
+    lib.pnx_queue_order_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.pnx_queue_order_f64.restype = C.c_int
     lib.pnx_release_staging.restype = C.c_int
     lib.pnx_device_count.restype = C.c_int
     lib.pnx_last_error.restype = C.c_int

@@ -106,9 +106,10 @@ def release_staging(device=0):
     check(load().pnx_release_staging(int(device)))
 
 
-def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, device, stream=None):
+def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nfev, cost, device, stream=None, order=None):
     """Enqueue a batched fit on HBM-resident torch tensors (asynchronous; caller synchronises).  float32 tensors
-    select the fp32-storage entry point."""
+    select the fp32-storage entry point.  `order`: optional int32 device tensor, a permutation of the voxel indices in which
+    the kernel's queue hands the voxels out (longest fits first hides the straggler tail; results do not depend on it)."""
     f32 = "float32" in str(getattr(y, "dtype", ""))
     b = np.ascontiguousarray(b, np.float32 if f32 else np.float64)
     if not getattr(opts, "per_voxel_p0_bounds", 0):
@@ -116,6 +117,10 @@ def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nf
     if isinstance(fixed, np.ndarray):
         fixed = np.ascontiguousarray(fixed, b.dtype)
     fn = load().pnx_curvefit_batch_f32 if f32 else load().pnx_curvefit_batch_f64
+    if order is not None:
+        if tuple(order.shape) != (int(n_vox),) or "int32" not in str(order.dtype):
+            raise ValueError("order must be an int32 device tensor of n_vox entries")
+        check(load().pnx_curvefit_queue_order(ptr(order)))
     check(fn(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
                                         ptr(fixed), ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost),
                                         MEM_DEVICE, int(device), stream))
@@ -331,6 +336,13 @@ def gather_rows_device(src, c, idx, n_sel, dst, device, stream=None):
 
 def scatter_rows_t_device(popt, idx, n_sel, k, n_total, pmap, device, stream=None):
     check(load().pnx_scatter_rows_t_f64(ptr(popt), ptr(idx), int(n_sel), int(k), int(n_total), ptr(pmap), int(device), stream))
+
+
+def queue_order_device(key, order, device, stream=None):
+    """order (int32 tensor) = voxel indices by descending `key` (float64 tensor of predicted evaluation counts), ties in index
+    order: what `curvefit_device(..., order=)` takes."""
+    check(load().pnx_queue_order_f64(ptr(key), int(key.numel()), ptr(order), int(device), stream))
+    return order
 
 
 def row_ss_tot_device(y, n, c, out, device, stream=None):

@@ -174,6 +174,9 @@ struct StreamLaunch {
     int phase = 0;
 };
 
+// pnx_curvefit_queue_order: the calling thread's NEXT device-mode fit pulls its voxels in this order
+static thread_local const int32_t *g_next_order = nullptr;
+
 static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y_d,
                            const double *p0, const double *lo, const double *hi, const double *fixed, double *popt_d,
                            double *pcov_d, int8_t *status_d, int32_t *nfev_d, double *cost_d, DeviceInfo *dev,
@@ -186,6 +189,10 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
         a.granule_shift = sl->granule_shift;
         a.stream_spins = sl->spins;
         a.phase = sl->phase;
+    }
+    if (!sl) {
+        a.order = g_next_order;
+        g_next_order = nullptr;
     }
     a.y = y_d;
     a.popt = popt_d;
@@ -881,6 +888,11 @@ int pnx_release_staging(int device) {
         g_sres[device].release();
         (void)hipSetDevice(cur);
     }
+    return PNX_OK;
+}
+
+int pnx_curvefit_queue_order(const int32_t *order_device) {
+    g_next_order = order_device;
     return PNX_OK;
 }
 

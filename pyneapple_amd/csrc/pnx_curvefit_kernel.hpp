@@ -63,6 +63,8 @@ struct CurvefitArgs {
     int32_t *nfev;
     double *cost;
     unsigned long long *queue;  // work-queue head, zeroed before launch
+    const int32_t *order;       // null, or (n_vox) a permutation: the queue's k-th pull fits voxel order[k] (longest fits first, see
+                                // pnx_curvefit_queue_order); never with a streamed launch (granules complete in index order)
     // Streamed launch (host-pointer calls, pnx_api.hip `curvefit_streamed`): ONE persistent kernel runs while the volume is
     // still being uploaded and its results are already being downloaded.  ctl != null selects the STREAM instantiation.
     StreamCtl *ctl;             // device memory: upload watermark, abort word, per-granule wave counts
@@ -766,6 +768,9 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
             }
         }
         vox = (long long)idx;
+        if constexpr (!STREAM) {
+            if (A.order) vox = A.order[idx];
+        }
         const double *yv = A.y + (size_t)vox * n_b;
         if (dma_ok) {
             // asynchronous refill: 16-byte global->LDS loads (no VGPR round trip, nothing waits here); they land

@@ -306,3 +306,40 @@ int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int devic
     return PNX_OK;
 }
 }
+
+
+// ---- queue order of a curve fit from a predictor of the evaluation counts (pnx_curvefit_queue_order) ------------
+namespace pnx {
+namespace {
+__global__ void iota_kernel(int32_t *v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+}  // namespace
+}  // namespace pnx
+
+extern "C" int pnx_queue_order_f64(const double *key, int64_t n, int32_t *order, int device, void *stream) {
+    using namespace pnx;
+    if (!key || !order || n < 0) return set_error(PNX_ERR_INVALID, "bad argument");
+    if (n == 0) return PNX_OK;
+    if (n >= ((int64_t)1 << 31)) return set_error(PNX_ERR_INVALID, "n=%lld: at most 2^31 - 1 voxels", (long long)n);
+    RS_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } tmp, keys_out, iota;
+    RS_HIP(hipMalloc(&keys_out.p, (size_t)n * sizeof(double)));
+    RS_HIP(hipMalloc(&iota.p, (size_t)n * sizeof(int32_t)));
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int32_t *)iota.p, (int)n);
+    RS_HIP(hipGetLastError());
+    size_t need = 0;
+    RS_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, key, (double *)keys_out.p, (const int32_t *)iota.p, order, (int)n, 0, 64, st));
+    RS_HIP(hipMalloc(&tmp.p, need ? need : 8));
+    // a radix sort is stable: voxels with equal keys keep their index order
+    RS_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, need, key, (double *)keys_out.p, (const int32_t *)iota.p, order, (int)n, 0, 64, st));
+    RS_HIP(hipStreamSynchronize(st));  // the temporaries are freed on return
+    return PNX_OK;
+}

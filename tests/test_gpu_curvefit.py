@@ -583,6 +583,49 @@ def test_two_stalled_uploads_in_a_row_cost_one_stall(gpu, monkeypatch, capfd):
     np.testing.assert_array_equal(third["popt"], good["popt"])
 
 
+def test_queue_order_changes_the_schedule_not_the_results(gpu):
+    """pnx_curvefit_queue_order: the kernel's k-th queue pull fits voxel order[k].  A voxel's arithmetic is its own, so any
+    permutation gives bit-identical results; the order made from a previous pass's evaluation counts (pnx_queue_order_f64:
+    descending, ties in index order) is what a refit of the same volume passes (C3: 34.3 -> 25.0 ms,
+    profiles/curvefit_order_probe.py).  The order applies to ONE call."""
+    import torch
+
+    from pyneapple_amd import api, synth
+
+    dev = torch.device("cuda", 0)
+    n_vox, n_b = 50000 + 13, 32
+    b, y = synth.make_torch("tri_reduced", n_vox, n_b, dev, sigma=0.01, seed=4)
+    names, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    k = len(names)
+    opts = api.make_opts("tri_reduced", n_b, max_nfev=250, ftol=1e-8, jac="fd")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(order=None):
+        out = (torch.empty((k, n_vox), dtype=torch.float64, device=dev), torch.empty((n_vox, k, k), dtype=torch.float64, device=dev),
+               torch.empty(n_vox, dtype=torch.int8, device=dev), torch.empty(n_vox, dtype=torch.int32, device=dev),
+               torch.empty(n_vox, dtype=torch.float64, device=dev))
+        api.curvefit_device(opts, n_vox, b, y, p0, lo, hi, None, *out, 0, s, order=order)
+        torch.cuda.synchronize()
+        return out
+
+    ref = run()
+    order = api.queue_order_device(ref[3].to(torch.float64), torch.empty(n_vox, dtype=torch.int32, device=dev), 0, s)
+    o = order.cpu().numpy()
+    nf = ref[3].cpu().numpy()
+    assert sorted(o.tolist()) == list(range(n_vox))                      # a permutation ...
+    assert (np.diff(nf[o]) <= 0).all()                                    # ... by descending count ...
+    same = np.diff(nf[o]) == 0
+    assert (np.diff(o)[same] > 0).all()                                   # ... ties in index order
+    for perm in (order, torch.randperm(n_vox, device=dev).to(torch.int32), torch.arange(n_vox - 1, -1, -1, device=dev, dtype=torch.int32)):
+        got = run(perm)
+        for a, r in zip(got, ref):
+            assert torch.equal(a, r) or bool(((a == r) | (a.isnan() & r.isnan())).all())
+    again = run()  # the order was for one call only
+    assert torch.equal(again[0], ref[0])
+    with pytest.raises(ValueError):
+        api.curvefit_device(opts, n_vox, b, y, p0, lo, hi, None, *ref, 0, s, order=order[:-1])
+
+
 def test_device_call_is_graph_capturable(gpu):
     """The device-pointer entry point only enqueues (a memset of its queue counter and two kernels): it can be captured
     into a HIP graph and replayed on new signal data, for callers that fit many small batches in a loop."""
