@@ -137,6 +137,20 @@ static int env_int(const char *name, int dflt, int lo, int hi) {
     return v < lo ? lo : (v > hi ? hi : (int)v);
 }
 
+// Helper threads of a host-array call.  One call uses an upload thread, one or two download threads and two page-touch
+// helpers; the plugin's n_gpus = N (one call per device at once) and callers with several volumes in flight multiply that,
+// on a CPU share of 16 cores per GPU.  The page-touch helpers only pay off while cores are idle: with two calls in flight each
+// gets one, with three or more none (the download threads touch their own pages then); PNX_HOST_TOUCHERS / _OUT_THREADS
+// set explicitly win.
+static std::atomic<int> g_host_calls(0);
+struct HostCallGuard {
+    int in_flight;
+    HostCallGuard() : in_flight(g_host_calls.fetch_add(1) + 1) {}
+    ~HostCallGuard() { g_host_calls.fetch_sub(1); }
+    int touchers() const { return getenv("PNX_HOST_TOUCHERS") ? env_int("PNX_HOST_TOUCHERS", 2, 0, 8) : (in_flight >= 3 ? 0 : (in_flight == 2 ? 1 : 2)); }
+    int out_threads() const { return getenv("PNX_STREAM_OUT_THREADS") ? env_int("PNX_STREAM_OUT_THREADS", 2, 1, 4) : (in_flight >= 4 ? 1 : 2); }
+};
+
 struct Carver {  // hands out 256-byte aligned pieces of one device slab
     char *base = nullptr;
     size_t off = 0;
@@ -446,7 +460,7 @@ template <typename T>
 static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double *bd, const T *y, const double *p0d,
                              const double *lod, const double *hid, const T *p0_pv, const T *lo_pv, const T *hi_pv,
                              const double *fxd, const T *fixed_pv, T *popt, T *pcov, int8_t *status, int32_t *nfev, T *cost,
-                             int gshift, DeviceInfo *dev, int device, hipStream_t user_stream) {
+                             int gshift, DeviceInfo *dev, int device, hipStream_t user_stream, const HostCallGuard &hg) {
     constexpr bool F32 = sizeof(T) == 4;
     const int n = o->n_free, n_b = o->n_b;
     const int n_fpv = fixed_pv ? o->n_fixed : 0;  // per-voxel fixed maps (n_fixed, n_vox): uploaded piece by piece like the signal
@@ -509,7 +523,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
 
     // the downloads are pageable copies (the runtime pins the destination pages piece by piece): two threads, each with its
     // own stream and every other granule, keep up with the kernel where one falls 13 ms behind (C3, profiles/stream_sweep.py)
-    const int n_out = env_int("PNX_STREAM_OUT_THREADS", 2, 1, 4);
+    const int n_out = hg.out_threads();
     if ((rc = res.ensure_streams(2 + n_out))) return rc;
     hipStream_t s_in = res.s[0], s_main = res.s[1];
     PNX_HIP(hipMemsetAsync(ctl, 0, ctl_bytes, s_main));
@@ -625,7 +639,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     const double stall_ms = env_int("PNX_STREAM_STALL_MS", 50, 1, 60000);
     bool stalled = false;
     StreamedTimes times;
-    rc = run_streamed(n_in, n_gran, n_out, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), stall_ms, env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000),
+    rc = run_streamed(n_in, n_gran, n_out, hg.touchers(), stall_ms, env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000),
                       ops, &stalled, trace ? &times : nullptr, now);
     (void)hipStreamSynchronize(s_in);  // nothing of this call is left on the kept streams
     (void)hipEventDestroy(ev_first);
@@ -713,6 +727,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         }
     }
 
+    HostCallGuard hg;  // this call is in flight from here on (helper-thread budget)
     // ---- host staging, streamed: one persistent kernel for the whole volume (curvefit_streamed above)
     {
         // granule = unit of the download (and of the completion flags): 256 Ki voxels for volumes of 2 Mi voxels and more,
@@ -743,7 +758,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         if (!cooling && env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
             nv < ((size_t)1 << 31) && nv * per_vox <= max_bytes) {
             rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, pv ? p0 : nullptr, pv ? lo : nullptr, pv ? hi : nullptr, fxd,
-                                      fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream);
+                                      fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream, hg);
             if (rc != kStreamRetry) return rc;
             static std::atomic<bool> warned(false);
             if (getenv("PNX_HOST_TRACE") || !warned.exchange(true))
@@ -872,7 +887,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.tcost, c * sizeof(T), hipMemcpyDeviceToHost, st));
         return PNX_OK;
     };
-    return run_pipeline(n_chunks, n_slots, env_int("PNX_HOST_KSTREAMS", 2, 1, 4), env_int("PNX_HOST_TOUCHERS", 2, 0, 8), device, (hipStream_t)stream, ops);
+    return run_pipeline(n_chunks, n_slots, env_int("PNX_HOST_KSTREAMS", 2, 1, 4), hg.touchers(), device, (hipStream_t)stream, ops);
 }
 
 extern "C" {
@@ -1102,7 +1117,8 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
             if (iters) PNX_HIP(hipMemcpyAsync(iters + off, S.i, c * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             return PNX_OK;
         };
-        int r = run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+        HostCallGuard hg;
+        int r = run_pipeline(n_chunks, n_slots, 1, hg.touchers(), P.device, st, ops);
         if (r || !defer) return r;
         int32_t cnt[2] = {0, 0};
         PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
@@ -1288,7 +1304,8 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
             }
             return PNX_OK;
         };
-        int r = run_pipeline(n_chunks, n_slots, 1, env_int("PNX_HOST_TOUCHERS", 2, 0, 8), P.device, st, ops);
+        HostCallGuard hg;
+        int r = run_pipeline(n_chunks, n_slots, 1, hg.touchers(), P.device, st, ops);
         if (r || !defer) return r;
         int32_t cnt[2] = {0, 0};
         PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
