@@ -72,7 +72,15 @@ def c4(m=1 << 17, verbose=True):
         print(f"oracle: {m / (time.perf_counter() - t):.0f} voxels/s", flush=True)
     c = coeff.cpu().numpy(); cr = o["coefficients"]
     err = np.abs(c - cr).max(axis=1) / np.maximum(np.abs(cr).max(axis=1), 1e-300)
-    return {"workload": "C4 NNLS 250 bins, reg_order 2, mu 0.02, 32 b-values, seed-fixed synthetic rows [0, n)", "n": m,
+    itg = it.cpu().numpy()
+    differ = np.flatnonzero((itg != o["iters"]) | ~((c > 0) == (cr > 0)).all(axis=1))
+    odd = [{"voxel": int(v), "iters_gpu": int(itg[v]), "iters_oracle": int(o["iters"][v]), "support_gpu": int((c[v] > 0).sum()),
+            "support_oracle": int((cr[v] > 0).sum()), "bins_only_gpu": np.flatnonzero((c[v] > 0) & ~(cr[v] > 0)).tolist(),
+            "bins_only_oracle": np.flatnonzero(~(c[v] > 0) & (cr[v] > 0)).tolist(), "coef_err": float(err[v]),
+            "rnorm_gpu": float(rn[v]), "rnorm_oracle": float(o["residual"][v]),
+            "largest_coefficient_on_a_differing_bin_rel_peak": float(max([abs(c[v, j]) for j in np.flatnonzero((c[v] > 0) != (cr[v] > 0))] + [abs(cr[v, j]) for j in np.flatnonzero((c[v] > 0) != (cr[v] > 0))] + [0.0]) / np.abs(cr[v]).max())}
+           for v in differ[:16]]
+    return {"voxels_with_a_different_path": odd,"workload": "C4 NNLS 250 bins, reg_order 2, mu 0.02, 32 b-values, seed-fixed synthetic rows [0, n)", "n": m,
             "status_equal": float((s8.cpu().numpy() == o["status"]).mean()), "iters_equal": float((it.cpu().numpy() == o["iters"]).mean()),
             "support_equal": float((((c > 0) == (cr > 0)).all(axis=1)).mean()), "coef_err_max": float(err.max()),
             "coef_err_median": float(np.median(err)), "max_passive_set": int((c > 0).sum(axis=1).max()),
