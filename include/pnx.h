@@ -177,6 +177,13 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  *     solve of such a plan); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
  *     this library never changes the algorithm silently;
  *   - anything else (dense regularisers, 33..128 measurements): Gram form (pnx_nnls.hip).
+ * n_bins <= 256 (PNX_ERR_UNSUPPORTED beyond; the reference has no such limit, model_functions/nnls.py:37-77).  Why 256 and not
+ * 512: every kernel gives a lane of the wavefront that owns a voxel four bins.  At eight, the block kernel's LDS copy of the
+ * basis is 32 x 514 doubles = 131 KB of a CU's 160 KB (66 KB now): two voxels in flight per CU instead of twelve, and it is 12
+ * against 8 waves that measured 6.48 against 5.18 M voxels/s; the general kernel is compiled to exactly the 128 registers that
+ * sixteen waves per CU allow, with 96 bytes of scratch already (hipcc 7.2, -O3), and eight bins per lane add the dual, the
+ * passive flags and the row of G of four more bins (>= 24 registers): its 12-wave build measured 3.63 against 4.42 M voxels/s.
+ * A 512-bin build would therefore be a separate, slower instantiation of both kernels; it is not there.
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;
 int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
