@@ -47,6 +47,13 @@ namespace pnx {
 constexpr int kLdsRows = PNX_NNLS_LDS_ROWS;  // rows of M kept in LDS (<= 64)
 constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
 constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
+// Row access that is "LDS or slab" by a (uniform or per-lane) row index.  Typed by address space: with plain pointers the compiler
+// folds the two cases into ONE flat access through a selected base pointer, and a flat access waits for both the LDS and the
+// vector-memory counter (round 4, found in the block kernel first: pnx_nnls_blk.hip; 15 flat accesses here: + 5-7 %).
+// (Also tried here and not kept: the block kernel's closed-form rotation of q and v_rsq-based rotation coefficients --
+// 5.09 -> 4.34 M voxels/s at 33 b-values: this kernel sits at exactly 128 registers, the extra scans spill.)
+typedef __attribute__((address_space(3))) double gen_lds_double;
+typedef __attribute__((address_space(1))) double gen_glb_double;
 constexpr int kGBatch = PNX_NNLS_GBATCH;  // rows of G in flight per lane in the dual update
 static_assert(kLdsRows <= kW, "LDS rows are owned by the first slot");
 
@@ -155,6 +162,8 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
     double *bc = Mlds + kLdsTri;      // broadcast buffer: position-indexed values of slot 0, read with a uniform address
     const int lane = threadIdx.x;
     double *Mg = A.Mglob + (size_t)blockIdx.x * kGlobTri;
+    gen_lds_double *MldsT = (gen_lds_double *)Mlds;
+    gen_glb_double *MgT = (gen_glb_double *)Mg;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
     const int m_total = nm + nreg;
 
@@ -421,17 +430,16 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 double a1[kSlots], a2[kSlots];
                 col_pass<false>(Mlds, Mg, p, lane, l, l, a1, a2);
                 const double inv = inv_lam;
-                double *rowp = (p < kLdsRows) ? (Mlds + tri(p)) : (Mg + (tri(p) - kLdsTri));
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) {
                     const int k = lane + kW * s;
-                    if (k < p) {
-                        const double r = -a1[s] * inv;
-                        rowp[k] = r;
-                        z[s] = x[s] + r * qn;
-                    } else if (k == p) {
-                        rowp[k] = inv;
-                        z[s] = qn * inv;
+                    if (k <= p) {
+                        const double r = k < p ? -a1[s] * inv : inv;
+                        if (p < kLdsRows)  // wave uniform
+                            MldsT[tri(p) + k] = r;
+                        else
+                            MgT[tri(p) - kLdsTri + k] = r;
+                        z[s] = k < p ? x[s] + r * qn : qn * inv;
                     }
                     if (binof(lane, s) == jmax) inP[s] = true;
                 }
@@ -508,7 +516,12 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                         mv[s] = 0;
                         pre[s] = carry;
                         if (kW * s < p) {
-                            if (i >= jj && i < p) mv[s] = (i < kLdsRows) ? Mlds[tri(i) + jj] : Mg[tri(i) - kLdsTri + jj];
+                            if (i >= jj && i < p) {
+                                if (i < kLdsRows)
+                                    mv[s] = MldsT[tri(i) + jj];
+                                else
+                                    mv[s] = MgT[tri(i) - kLdsTri + jj];
+                            }
                             const double sc = wave_incl_scan(mv[s] * mv[s]);
                             pre[s] = sc + carry;
                             carry += rl(sc, 63);
@@ -539,11 +552,16 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                                                     : __builtin_amdgcn_readlane(pidx[3], jj & 63);
                     {
                         double car[kSlots];
-                        const double *rowj = (jj < kLdsRows) ? (Mlds + tri(jj)) : (Mg + (tri(jj) - kLdsTri));
 #pragma unroll
                         for (int s = 0; s < kSlots; ++s) {
                             const int c = lane + kW * s;
-                            car[s] = (c < jj) ? rowj[c] : 0.0;
+                            car[s] = 0.0;
+                            if (c < jj) {
+                                if (jj < kLdsRows)  // wave uniform
+                                    car[s] = MldsT[tri(jj) + c];
+                                else
+                                    car[s] = MgT[tri(jj) - kLdsTri + c];
+                            }
                         }
                         double carq = jj < kW ? rl(q[0], jj & 63) : jj < 2 * kW ? rl(q[1], jj & 63)
                                     : jj < 3 * kW ? rl(q[2], jj & 63) : rl(q[3], jj & 63);
@@ -553,16 +571,22 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                             constexpr int si = decltype(S)::value;
                             const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
                             const double qnx = rl(qsh[si], i & 63);
-                            const double *rown = (i + 1 < kLdsRows) ? (Mlds + tri(i + 1)) : (Mg + (tri(i + 1) - kLdsTri));
-                            double *rowo = (i < kLdsRows) ? (Mlds + tri(i)) : (Mg + (tri(i) - kLdsTri));
 #pragma unroll
                             for (int s = 0; s <= si; ++s) {
                                 const int c = lane + kW * s;
                                 if (c <= i) {
-                                    const double nxt = rown[c < jj ? c : c + 1];
+                                    const int cn = c < jj ? c : c + 1;
+                                    double nxt;
+                                    if (i + 1 < kLdsRows)  // wave uniform
+                                        nxt = MldsT[tri(i + 1) + cn];
+                                    else
+                                        nxt = MgT[tri(i + 1) - kLdsTri + cn];
                                     const double outv = c_ * car[s] - s_ * nxt;
                                     car[s] = s_ * car[s] + c_ * nxt;
-                                    rowo[c] = outv;
+                                    if (i < kLdsRows)
+                                        MldsT[tri(i) + c] = outv;
+                                    else
+                                        MgT[tri(i) - kLdsTri + c] = outv;
                                 }
                             }
                             const double oq = c_ * carq - s_ * qnx;
