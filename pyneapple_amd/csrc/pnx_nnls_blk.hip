@@ -23,11 +23,19 @@
 //     a row access is contiguous); rows >= 48 and the Givens sweep of a removal go row by row with the loads of 4 - 12
 //     rows in flight.  Position-indexed vectors hold 128 positions (two register slots): a voxel whose passive set wants
 //     to grow beyond that (about one in 10^4 on the reference workload) is handed to pnx_nnls.hip through a list.
-// What bounds it (profiles/r03_*): VALU issue -- 64 k instructions per voxel at ~4.2 cycles, the SIMDs 76 % busy at three
-// waves each -- and the latency of what a wave does in sequence; every fp64 FMA of the B^T r product (128 per lane and
-// outer iteration) is needed, so the remaining lever is the instruction count around them.  The kernel arguments are read
-// from the kernarg segment where they are used, the LDS scratch sits below 64 KB (DS offsets as immediates), phases take
-// a fresh copy of the lane id: all three keep hoisted values out of registers the hot loops need.
+// Round 4 took a third of the vector instructions out (64 k -> 43 k per voxel, 6.65 -> 8.6 M voxels/s on the reference workload):
+//   * a removal's rotation coefficients travel through LDS (one broadcast read per row instead of four v_readlane), q is rotated
+//     in closed form (a prefix sum), row masks are scalar, shifts by one position are DPP moves;
+//   * the dual gathers x by bin through LDS addresses kept per passive position, and its stencil passes ride on the round trips
+//     of the gathers and of the B^T r product; passive flags are scalar wave masks;
+//   * "LDS or slab" accesses are typed by address space (the compiler folds plain pointers into flat accesses that wait for
+//     both counters);
+//   * a rejected candidate column sets its passive flag and the dual is evaluated again -- no loop around the append, which had
+//     cost every outer iteration 128 bytes of scratch per lane: the kernel has none left.
+// What bounds it (profiles/r04_*): VALU (66 % of a SIMD at three waves) and LDS (70 %) together; every fp64 FMA of the B^T r
+// product (128 per lane and outer iteration) is needed, so the lever stays the instruction count around them.  The kernel
+// arguments are read from the kernarg segment where they are used, the LDS scratch sits below 64 KB (DS offsets as immediates),
+// phases take a fresh copy of the lane id: all three keep hoisted values out of registers the hot loops need.
 // One wavefront owns one voxel; waves pull voxels from an atomic queue and never meet after the basis is staged.
 #include <hip/hip_runtime.h>
 
@@ -44,26 +52,20 @@ namespace pnx {
 constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
 constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
 #ifndef PNX_BLK_WAVES
-#define PNX_BLK_WAVES 12  // 168 registers per wave.  16 waves (128 registers): 62-83 spilled registers and 17 % slower; with the row-wise
-                         // path for rows >= 48 taken out (33 spills, wrong results) still only 3.5 % ahead of 12 waves
+#define PNX_BLK_WAVES 12  // 168 registers per wave, no scratch.  16 waves (128 registers, 24 rows of M in LDS): 128 bytes of scratch and
+                         // 7.2 against 8.2 M voxels/s (round 4; round 3: 62-83 spilled registers, 17 % slower)
 #endif
 constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU
 constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
 constexpr int kPS = 2;                      // register slots of a position-indexed vector: positions < 128
 constexpr int kMaxPos = kPS * kW;           // a voxel whose passive set wants to grow beyond that is handed to pnx_nnls.hip
 constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
-// per-wave LDS scratch, in doubles: ps[128] (ints) bin by position | xbuf[264] x by bin with halo.  xbuf is also the staging
-// buffer of the M sweeps, and -- in the part of the dual that runs before the stencil -- holds xs[128] (x by position) and
-// rb[32] (residual of the measurements): every LDS byte not spent here keeps a row of M on the chip
-#ifndef PNX_BLK_DUAL2
-#define PNX_BLK_DUAL2 1  // round 4: x is gathered by bin out of xbuf, the residual of the measurements has a place of its own, the two
-                         // stencil passes ride on the round trips of the column gathers and of the B^T r product
-#endif
+// per-wave LDS scratch, in doubles: ps[128] (ints): per passive position the LDS byte address of its bin's entry in xbuf |
+// xbuf[264]: x by bin with a halo of two (then t = R x by bin; the (c, s) pairs of a removal; the staging vector of M^T q; its
+// last four doubles: the list of rejected columns) | rb[32]: residual of the measurements.  Every LDS byte not spent here keeps
+// a row of M on the chip
 constexpr int kPadBin = kNnlsMaxBins;  // bin of the padding positions: column 256 of the LDS basis and xbuf[2 + 256] are zero
-constexpr int kScr = kMaxPos / 2 + kXbuf + (PNX_BLK_DUAL2 ? 32 : 0);
-#ifndef PNX_BLK_ROT
-#define PNX_BLK_ROT 1
-#endif
+constexpr int kScr = kMaxPos / 2 + kXbuf + 32;
 #ifndef PNX_BLK_LDS_ROWS
 #define PNX_BLK_LDS_ROWS 32
 #endif
@@ -260,101 +262,6 @@ template <int NS> __device__ __forceinline__ void shift_down_dpp_i(const int (&a
 }
 
 // ---- products with the LDS-resident basis ------------------------------------------------------------------
-// stage x / pidx by position (zeros behind position p up to the end of its slot)
-__device__ __forceinline__ void stage_positions(double *xs, lds_int *ps, int p, int lane, const double (&x)[kPS],
-                                                const int (&pidx)[kPS]) {
-#pragma unroll
-    for (int s = 0; s < kPS; ++s) {
-        const int i = lane + kW * s;
-        if (kW * s <= p && i < kMaxPos) {  // wave uniform
-            xs[i] = i < p ? x[s] : 0.0;
-            ps[i] = i < p ? pidx[s] : 0;
-        }
-    }
-}
-// every lane: (B_P x_P)[m], m = lane & 31.  Half wave h takes the positions h, h + 2, ...; the trip count is the same for
-// both halves (the staged arrays are zero padded), so the loops are scalar ones.  Eight positions per half and step: the
-// x / bin reads of a step and then its eight column gathers are in flight together.
-__device__ __forceinline__ double b_times_xp(const double *Bl, const double *xs, const lds_int *ps, int p, int lane) {
-    const int m = lane & 31, h = lane >> 5;
-    const double *Bm = Bl + m * kBStride;
-    const double *xh = xs + h;
-    const lds_int *ph = ps + h;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int i = 0; i < p; i += 16) {  // the staged arrays are zero padded to the end of the slot (a multiple of 16)
-        double xv[8], bv[8];
-        int jv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            xv[u] = xh[i + 2 * u];
-            jv[u] = ph[i + 2 * u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) bv[u] = Bm[jv[u]];
-        a0 = fma(xv[0], bv[0], a0);
-        a1 = fma(xv[1], bv[1], a1);
-        a2 = fma(xv[2], bv[2], a2);
-        a3 = fma(xv[3], bv[3], a3);
-        a0 = fma(xv[4], bv[4], a0);
-        a1 = fma(xv[5], bv[5], a1);
-        a2 = fma(xv[6], bv[6], a2);
-        a3 = fma(xv[7], bv[7], a3);
-    }
-    return swap_add32((a0 + a1) + (a2 + a3));
-}
-// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m], v = 32 doubles in LDS.  Two groups of four rows (eight ds_read_b128
-// each) alternate: one is in flight while the other is consumed.
-__device__ __forceinline__ void bt_times(const double *Bl, const double *v, int lane, double (&out)[kSlots]) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) out[s] = 0;
-    const double *col = Bl + 2 * lane;
-    double2 c0[4], c1[4], d0[4], d1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
-        c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
-    }
-#pragma unroll 1
-    for (int m = 0; m < kBMeas; m += 8) {
-        const double *nx = col + (m + 4) * kBStride;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
-            d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
-        }
-        {
-            const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
-            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
-            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[0] = fma(c0[r].x, vv[r], out[0]);
-                out[1] = fma(c0[r].y, vv[r], out[1]);
-                out[2] = fma(c1[r].x, vv[r], out[2]);
-                out[3] = fma(c1[r].y, vv[r], out[3]);
-            }
-        }
-        const double *ny = col + ((m + 8) & (kBMeas - 1)) * kBStride;  // the last step re-reads rows 0 .. 3 (unused)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            c0[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride);
-            c1[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride + 128);
-        }
-        {
-            const double2 v01 = *reinterpret_cast<const double2 *>(v + m + 4);
-            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 6);
-            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[0] = fma(d0[r].x, vv[r], out[0]);
-                out[1] = fma(d0[r].y, vv[r], out[1]);
-                out[2] = fma(d1[r].x, vv[r], out[2]);
-                out[3] = fma(d1[r].y, vv[r], out[3]);
-            }
-        }
-    }
-}
-
 #ifdef PNX_NNLS_STAMP
 __device__ unsigned long long g_blk_rejects = 0;  // rejected candidate columns since the library was loaded (diagnostic builds)
 #define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
@@ -613,7 +520,6 @@ template <int NI> __device__ __forceinline__ void block_row(const MRef &M, int I
 // Returns false when the column is rejected (nothing changed).
 // One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
 // the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
-#if PNX_BLK_DUAL2
 // What an append needs that does not depend on the candidate, requested before the arg-max so that its latency hides behind it:
 // the bins of the positions in column layout (as byte offsets into a row of G).  (The blocks of M that live in the slab would
 // qualify too, but held across the arg-max they push the append out of its registers: 64 -> 256 bytes of scratch, measured.)
@@ -623,13 +529,10 @@ __device__ __forceinline__ void append_prefetch(const lds_int *ps, int lb, unsig
 #pragma unroll
     for (int K = 0; K < NI; ++K) goff[K] = (unsigned)(ps[8 * K + lb] - ps_base);  // ps holds LDS addresses of x by bin
 }
-#endif
 template <int NI>
 __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const lds_int *ps, int lane, int la, int lb, int jmax,
                                            double wj, VoxState &S
-#if PNX_BLK_DUAL2
                                            , const unsigned (&goff)[NI]
-#endif
 ) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const double *grow = G + (size_t)jmax * kNnlsMaxBins;
@@ -641,12 +544,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     double gc[NI];
 #pragma unroll
     for (int K = 0; K < NI; ++K) {  // no mask: behind position p the staged bins are 0 and the columns of M are zero
-#if PNX_BLK_DUAL2
         gc[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + goff[K]);
-#else
-        const int k = 8 * K + lb;
-        gc[K] = grow[CK(ps[k], kNnlsMaxBins, 3, k)];
-#endif
     }
     double rK[NI];  // column sums of l^T M, lane (a, b) holds the partial sum over its rows of column 8 K + b
 #pragma unroll
@@ -777,7 +675,6 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     return true;
 }
 
-#if PNX_BLK_DUAL2
 constexpr int kMaxRej = 8;  // rejected columns an outer iteration can remember (the four spare doubles behind xbuf's halo)
 // The candidate step of an outer iteration: largest positive dual (ties: lowest bin), then the append.  Returns 0 when no dual
 // is positive (KKT satisfied), 1 when the column entered, 2 when it was rejected, 3 when it was rejected and the list is full.
@@ -830,7 +727,6 @@ __device__ __forceinline__ int candidate(const double *G, const MRef &M, const l
     for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;
     return 2;
 }
-#endif
 
 // z = M^T q
 template <int NI>
@@ -913,12 +809,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     double *Bl = dyn_lds + kBlkWaves * kScr;
     lds_int *ps = reinterpret_cast<lds_int *>(scr);                    // [128] bin by position
     double *xbuf = scr + kMaxPos / 2;                                  // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
-#if PNX_BLK_DUAL2
     double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
-#else
-    double *xs = xbuf;                                                 // [128] x by position: dead before the stencil fills xbuf
-    double *rb = xbuf + kMaxPos;                                       // [32] residual of the measurements: likewise
-#endif
     MRef M;
     M.g = (glb_double *)(kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab);
     M.l = (lds_double *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles);
@@ -964,40 +855,14 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             COUNT(5, S.p);
             COUNT(6, S.p > 48 ? 1 : 0);
             COUNT(7, S.p > 64 ? 1 : 0);
-#if PNX_BLK_DUAL2
             {
                 const int ld = fresh(lane);
                 KArgs *K = kargs();
                 const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
                 dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, ld, yreg, S, w);
             }
-#else
-            {
-                const int ld = fresh(lane);
-                lds_order();
-                stage_positions(xs, ps, S.p, ld, S.x, S.pidx);
-                lds_order();
-                const double bx = b_times_xp(Bl, xs, ps, S.p, ld);
-                if (ld < kBMeas) rb[ld] = yreg - bx;
-                lds_order();
-                STAMP(9);
-                bt_times(Bl, rb, ld, w);
-                lds_order();
-                STAMP(10);
-                double u[kSlots];
-                KArgs *K = kargs();
-                const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
-                reg_terms<true>(xbuf, rc, K->rhb, n, S.p, ld, S.x, S.pidx, u, nullptr);
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    w[s] -= u[s];
-                    if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s])) w[s] = -INFINITY;
-                }
-            }
-#endif
             STAMP(1);
 
-#if PNX_BLK_DUAL2
             bool accepted = false;
             {
                 if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: hand the voxel over unless it is done
@@ -1027,46 +892,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     accepted = r == 1;
                 }
             }
-#else
-            bool accepted = false;
-            for (;;) {
-                // ---- largest positive w_j (ties: lowest bin)
-                const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-                if (!(best > 0)) break;  // KKT satisfied
-                // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
-                int jmax = kNone;
-                {
-                    const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
-                    const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
-                    const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
-                    const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
-                    const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
-                    const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
-                    const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
-                    jmax = lo < hi ? lo : hi;
-                }
-                if (jmax == kNone) break;  // cannot happen (some lane holds the maximum); never index G with it
-                if (S.p >= kMaxPos) {      // no room for another column in this kernel's registers
-                    status = kBail;
-                    break;
-                }
-                const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
-                const int lc = fresh(lane);
-                const double *Gp = kargs()->G;
-                if (nI <= 2)
-                    accepted = try_append<2>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
-                else if (nI <= 4)
-                    accepted = try_append<4>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
-                else
-                    accepted = try_append<6>(Gp, M, ps, lc, lc >> 3, lc & 7, jmax, best, S);
-                if (accepted) break;
-                COUNT(2, 1);
-                // reject: w[j] = 0 and look for the next largest
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s)
-                    if (binof(lane, s) == jmax) w[s] = 0.0;
-            }
-#endif
             STAMP(2);
             if (!accepted) break;
             STAMP(3);
@@ -1120,7 +945,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                     const int pp = __builtin_amdgcn_readfirstlane(S.p);
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-#if PNX_BLK_ROT
                     // Round 4: the rotation coefficients travel through LDS (one broadcast ds_read_b128 per row instead of
                     // four v_readlane), q is rotated in closed form (the carried combination of q is a prefix sum:
                     // carq_i = sum_{k = jj .. i} m_k q_k / a_i), row masks are scalar (no v_cmp), shifts are DPP moves;
@@ -1268,145 +1092,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                             for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{}, SlotTag<1>{});
                         }
                     }
-#else
-                    double mv[kPS], pre[kPS], car[kPS];
-                    double carry = 0;
-                    wave_sync();
-                    {
-                        const int jbase = moff(jj);
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s) {  // column jj (rows jj ..) and row jj (columns < jj): both reads in flight
-                            const int i = lane + kW * s;
-                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? (i < kLdsM ? M.l[i < kLdsM ? moff(i) + jj : 0] : M.g[CK(moff(i) + jj, kMSlab, 9, i)]) : 0.0;
-                            car[s] = (i < jj) ? M.ld(jj, jbase + i) : 0.0;
-                        }
-                    }
-                    // the first rows of the rotation sweep ride on the same round trip (their loads do not depend on the
-                    // coefficients computed below); rows < 64 only: one register per row and lane
-                    constexpr int kFirst = 12;
-                    const int e0 = (pp - 1) < kW ? (pp - 1) : kW;
-                    const int nfirst = e0 - jj < 0 ? 0 : (e0 - jj < kFirst ? e0 - jj : kFirst);
-                    double nx0[kFirst];
-#pragma unroll
-                    for (int r = 0; r < kFirst; ++r) {
-                        const int row = jj + r + 1 < pp ? jj + r + 1 : pp - 1;  // clamped: the surplus loads are not used
-                        nx0[r] = M.ld(row, moff(row) + (lane < jj ? lane : lane + 1));
-                    }
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s) {
-                        pre[s] = carry;
-                        if (kW * s < pp) {
-                            const double sc = wave_incl_scan(mv[s] * mv[s]);
-                            pre[s] = sc + carry;
-                            carry += rl(sc, 63);
-                        }
-                    }
-                    double mnext[kPS], prenext[kPS];
-                    shift_down(mv, mnext, lane);
-                    shift_down(pre, prenext, lane);
-                    double cs[kPS], sn[kPS];
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s) {
-                        const int i = lane + kW * s;
-                        cs[s] = 1.0;
-                        sn[s] = 0.0;
-                        if (i >= jj && i < pp - 1) {
-                            // a = sqrt(pre) (the first carried value keeps its sign), r = sqrt(prenext): c = m_next / r, s = a / r
-                            const double ir = prenext[s] > 0 ? rsqrt_nr(prenext[s]) : 0.0;
-                            const double a = (i == jj) ? mv[s] : (pre[s] > 0 ? pre[s] * rsqrt_nr(pre[s]) : 0.0);
-                            if (prenext[s] > 0) {
-                                cs[s] = mnext[s] * ir;
-                                sn[s] = a * ir;
-                            }
-                        }
-                    }
-                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
-                                                : __builtin_amdgcn_readlane(S.pidx[1], jj & 63);
-                    {
-                        double carq = jj < kW ? rl(S.q[0], jj & 63) : rl(S.q[1], jj & 63);
-                        double qsh[kPS];
-                        shift_down(S.q, qsh, lane);  // qsh[i] = q[i + 1]
-                        // row i of the new factor from the carried combination and old row i + 1 (column jj dropped);
-                        // the loads of a batch of rows are in flight before its first rotation
-                        auto rows = [&](int i, auto T, auto NB) {
-                            constexpr int si = decltype(T)::value;
-                            constexpr int nb = decltype(NB)::value;
-                            double nx[nb][si + 1];
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) {
-                                const int nbase = moff(i + r + 1);
-#pragma unroll
-                                for (int s = 0; s <= si; ++s) {
-                                    const int c = lane + kW * s;
-                                    nx[r][s] = M.ld(i + r + 1, nbase + (c < jj ? c : c + 1));
-                                }
-                            }
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) {
-                                const double c_ = rl(cs[si], (i + r) & 63), s_ = rl(sn[si], (i + r) & 63);
-                                const double qnx = rl(qsh[si], (i + r) & 63);
-                                const int obase = moff(i + r);
-#pragma unroll
-                                for (int s = 0; s <= si; ++s) {
-                                    const int c = lane + kW * s;
-                                    if (c <= i + r) {
-                                        const double outv = c_ * car[s] - s_ * nx[r][s];
-                                        car[s] = s_ * car[s] + c_ * nx[r][s];
-                                        M.st(i + r, obase + c, outv);
-                                    }
-                                }
-                                const double oq = c_ * carq - s_ * qnx;
-                                carq = s_ * carq + c_ * qnx;
-                                if (lane == ((i + r) & 63)) S.q[si] = oq;
-                            }
-                        };
-                        const int hi = pp - 1;
-                        STAMP(11);
-                        COUNT(3, 1);
-                        COUNT(4, hi - jj);
-#pragma unroll
-                        for (int r = 0; r < kFirst; ++r) {  // the prefetched rows
-                            if (r >= nfirst) break;
-                            const int i = jj + r;
-                            const double c_ = rl(cs[0], i & 63), s_ = rl(sn[0], i & 63);
-                            const double qnx = rl(qsh[0], i & 63);
-                            if (lane <= i) {
-                                const double outv = c_ * car[0] - s_ * nx0[r];
-                                car[0] = s_ * car[0] + c_ * nx0[r];
-                                M.st(i, moff(i) + lane, outv);
-                            }
-                            const double oq = c_ * carq - s_ * qnx;
-                            carq = s_ * carq + c_ * qnx;
-                            if (lane == (i & 63)) S.q[0] = oq;
-                        }
-                        {   // further rows < 64: eight per step
-                            const int e = hi < kW ? hi : kW;
-                            int i = jj + nfirst;
-                            for (; i + 8 <= e; i += 8) rows(i, SlotTag<0>{}, SlotTag<8>{});
-                            if (i + 4 <= e) {
-                                rows(i, SlotTag<0>{}, SlotTag<4>{});
-                                i += 4;
-                            }
-                            for (; i < e; ++i) rows(i, SlotTag<0>{}, SlotTag<1>{});
-                        }
-                        if (hi > kW) {
-                            int i = jj > kW ? jj : kW;
-                            for (; i + 4 <= hi; i += 4) rows(i, SlotTag<1>{}, SlotTag<4>{});
-                            for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{});
-                        }
-                    }
-#endif
                     // ---- drop position jj from x / pidx
                     {
                         double xsh[kPS];
                         int psh[kPS];
-#if PNX_BLK_ROT
                         shift_down_dpp(S.x, xsh);
                         shift_down_dpp_i(S.pidx, psh);
-#else
-                        shift_down(S.x, xsh, lane);
-                        shift_down_i(S.pidx, psh, lane);
-#endif
 #pragma unroll
                         for (int s = 0; s < kPS; ++s) {
                             const int i = lane + kW * s;
@@ -1467,7 +1158,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         double xb[kSlots] = {0, 0, 0, 0};
         double rn;
         if (status == 1) {
-#if PNX_BLK_DUAL2
             double tt = 0;
             KArgs *K = kargs();
             const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
@@ -1485,20 +1175,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
             xb[1] = wl.mid.y;
             xb[2] = wh.mid.x;
             xb[3] = wh.mid.y;
-#else
-            double tt = 0, dummy[kSlots];
-            lds_order();
-            KArgs *K = kargs();
-            const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
-            reg_terms<false>(xbuf, rc, K->rhb, n, S.p, lane, S.x, S.pidx, dummy, &tt);  // leaves x in bin order in xbuf
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof(lane, s)];
-            lds_order();
-            stage_positions(xs, ps, S.p, lane, S.x, S.pidx);
-            lds_order();
-            const double bx = b_times_xp(Bl, xs, ps, S.p, lane);
-            lds_order();
-#endif
             const double r = lane < kBMeas ? yreg - bx : 0.0;
             rn = sqrt(wave_sum(fma(r, r, tt)));
         } else
