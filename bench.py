@@ -131,57 +131,23 @@ def launch(args, argv) -> int:
 
 
 def _cpulist(text):
-    out = set()
-    for part in text.strip().split(","):
-        if not part:
-            continue
-        a, _, b = part.partition("-")
-        out.update(range(int(a), int(b or a) + 1))
-    return out
+    from pyneapple_amd.sharding import cpulist
+
+    return cpulist(text)
 
 
 def _fmt_cpus(cpus):
-    c = sorted(cpus)
-    runs, i = [], 0
-    while i < len(c):
-        j = i
-        while j + 1 < len(c) and c[j + 1] == c[j] + 1:
-            j += 1
-        runs.append(str(c[i]) if i == j else f"{c[i]}-{c[j]}")
-        i = j + 1
-    return ",".join(runs)
+    from pyneapple_amd.sharding import fmt_cpus
+
+    return fmt_cpus(cpus)
 
 
 def gpu_numa_cpus(index):
-    """CPUs local to the `index`-th GPU, read from sysfs only (KFD topology -> PCI device -> local_cpulist): nothing here
-    touches the GPU, so it can run before the affinity is set and before HIP starts its helper threads."""
-    import glob
+    """CPUs local to the `index`-th GPU, read from sysfs only (pyneapple_amd/sharding.py): nothing here touches the GPU, so it
+    can run before the affinity is set and before HIP starts its helper threads."""
+    from pyneapple_amd.sharding import gpu_numa_cpus as g
 
-    gpus = []
-    for d in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda q: int(os.path.basename(q))):
-        try:
-            props = dict(l.split(None, 1) for l in open(os.path.join(d, "properties")).read().splitlines() if " " in l)
-        except OSError:
-            continue
-        if int(props.get("simd_count", "0")) > 0:
-            gpus.append(props)
-    vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-    if vis:
-        try:
-            gpus = [gpus[int(v)] for v in vis.split(",") if v.strip() != ""]
-        except (ValueError, IndexError):
-            return None, None
-    if index >= len(gpus):
-        return None, None
-    loc, dom = int(gpus[index].get("location_id", "0")), int(gpus[index].get("domain", "0"))
-    bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
-    base = f"/sys/bus/pci/devices/{bdf}"
-    try:
-        node = int(open(base + "/numa_node").read())
-        cpus = _cpulist(open(base + "/local_cpulist").read())
-    except (OSError, ValueError):
-        return None, None
-    return node, cpus
+    return g(index)
 
 
 def pin_rank_to_gpu_numa(local_rank, local_world, share_gpu=False):

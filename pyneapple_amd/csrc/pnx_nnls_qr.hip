@@ -398,7 +398,7 @@ struct QrBigArgs {
 
 __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
     const QrArgs &A = BA.a;
-    __shared__ double abuf[kQM], lbuf[kQM];
+    __shared__ double lbuf[kQM];  // (Q^T v) by position, read back with uniform addresses
     double *Qt = BA.slab + (size_t)blockIdx.x * kQrSlab;  // [kQM][kQST]  Qt[i][m]: column i of Q
     double *Rc = Qt + (size_t)kQM * kQST;                 // [kQM][kQST]  Rc[k][i] = R[i][k]
     const int lane = threadIdx.x;

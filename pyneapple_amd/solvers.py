@@ -17,6 +17,7 @@ from typing import Any
 import numpy as np
 
 from . import api
+from .sharding import pinned_to_gpu
 from ._compat import HAVE_PYNEAPPLE, CurveFitBase, NNLSBase, PixelResultsView, RefBaseSolver
 
 _CURVEFIT_MESSAGES = {
@@ -334,8 +335,10 @@ class HipCurveFitSolver(CurveFitBase):
                 fv = np.ascontiguousarray(fv[:, sl])
             pv = (np.ascontiguousarray(p0[:, sl]), np.ascontiguousarray(lo[:, sl]),
                   np.ascontiguousarray(hi[:, sl])) if per_voxel else (p0, lo, hi)
-            return api.curvefit(self._kernel_model, xdata, ydata[sl], *pv, fixed_vals=fv,
-                                device=_shard_device(self.device, k), out={key: v[sl] for key, v in full.items()}, **kw)["popt"]
+            dev_k = _shard_device(self.device, k)
+            with pinned_to_gpu(dev_k):  # this thread and the call's helper threads stay on the NUMA node of their GPU
+                return api.curvefit(self._kernel_model, xdata, ydata[sl], *pv, fixed_vals=fv,
+                                    device=dev_k, out={key: v[sl] for key, v in full.items()}, **kw)["popt"]
 
         with ThreadPoolExecutor(len(parts)) as ex:  # ctypes releases the GIL during the call
             popts = list(ex.map(work, range(len(parts))))
@@ -423,9 +426,14 @@ class HipNNLSSolver(NNLSBase):
             # every result is voxel-major: the shards write into row ranges of the full arrays (the spectra are 2 KB per voxel)
             res = {"coefficients": np.empty((self.n_pixels, basis.shape[1]), signal.dtype), "residual": np.empty(self.n_pixels, signal.dtype),
                    "status": np.empty(self.n_pixels, np.int8), "iters": np.empty(self.n_pixels, np.int32)}
+            def work(k):
+                dev_k = _shard_device(self.device, k)
+                with pinned_to_gpu(dev_k):  # this thread and the call's helper threads stay on the NUMA node of their GPU
+                    api.nnls(basis, reg, signal[parts[k][0]:parts[k][1]], max_iter, dev_k,
+                             out={key: v[parts[k][0]:parts[k][1]] for key, v in res.items()})
+
             with ThreadPoolExecutor(len(parts)) as ex:
-                list(ex.map(lambda k: api.nnls(basis, reg, signal[parts[k][0]:parts[k][1]], max_iter, _shard_device(self.device, k),
-                                               out={key: v[parts[k][0]:parts[k][1]] for key, v in res.items()}), range(len(parts))))
+                list(ex.map(work, range(len(parts))))
         status = res["status"]
         self.pixel_results_ = PixelResultsView(
             res["coefficients"], None, status == 1,

@@ -76,3 +76,23 @@ def test_shards_of_the_volume_are_the_volume_and_fit_identically(oracle):
     left = oracle.curvefit("tri_reduced", b, parts[0][-40:].numpy(), p0, lo, hi)
     right = oracle.curvefit("tri_reduced", b, parts[1][:40].numpy(), p0, lo, hi)
     np.testing.assert_array_equal(np.concatenate([left["popt"], right["popt"]], axis=1), ref["popt"])
+
+
+def test_pinned_to_gpu_is_a_harmless_no_op_without_numa_information():
+    """The plugin's per-device threads pin themselves to their GPU's NUMA node (sysfs only).  In this container there is no KFD
+    topology: the context manager must leave the mask alone, and restore it where it did change it."""
+    import os
+
+    from pyneapple_amd.sharding import cpulist, fmt_cpus, gpu_numa_cpus, pinned_to_gpu
+
+    before = os.sched_getaffinity(0)
+    node, cpus = gpu_numa_cpus(0)
+    with pinned_to_gpu(0) as pin:
+        inside = os.sched_getaffinity(0)
+        assert inside <= before and inside
+        if cpus is None or not (cpus & before):
+            assert inside == before and pin.prev is None
+    assert os.sched_getaffinity(0) == before
+    with pinned_to_gpu(63):  # no such GPU
+        assert os.sched_getaffinity(0) == before
+    assert cpulist("0-2,5\n") == {0, 1, 2, 5} and fmt_cpus({0, 1, 2, 5}) == "0-2,5"

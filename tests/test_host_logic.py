@@ -205,7 +205,7 @@ def test_solver_n_gpus_sharding_reassembles_rows(monkeypatch):
                                   bounds={"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}, n_gpus=4, device=2)
     d1 = np.linspace(0.005, 0.05, n_vox)
     s.fit(b, y, pixel_fixed_params={"D1": d1})
-    assert [c[0] for c in calls] == [2, 3, 4, 5] and sum(c[1] for c in calls) == n_vox
+    assert sorted(c[0] for c in calls) == [2, 3, 4, 5] and sum(c[1] for c in calls) == n_vox  # the shards run in threads: any order
     assert all(c[3] == (1, c[1]) for c in calls)  # the fixed map was sliced with the rows
     np.testing.assert_array_equal(s.params_["f1"], d1)            # row 0 carried the fixed map through
     np.testing.assert_array_equal(s.params_["D2"], y[:, 0])       # voxel order preserved
