@@ -173,8 +173,8 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  *   - reg = one of the reference's banded matrices (model_functions/nnls.py:46-85, orders 1-3) and n_meas <= 32 (every
  *     configuration the reference ships): basis resident in LDS, residual-form dual (csrc/pnx_nnls_blk.hip);
  *   - no regulariser / an all-zero one (reg_order = 0, the reference default): QR form (pnx_nnls_qr.hip) -- Q and R in LDS
- *     up to 64 measurements, in a per-wave global slab from 65 to 128 (264 KB per resident wave, allocated on the first
- *     solve of such a plan); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
+ *     up to 32 measurements, in a per-wave global slab from 33 to 128 (264 KB per resident wave, allocated on the first
+ *     solve of such a plan; up to round 3 more than 64 measurements were refused); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
  *     this library never changes the algorithm silently;
  *   - anything else (dense regularisers, 33..128 measurements): Gram form (pnx_nnls.hip).
  * n_bins <= 256 (PNX_ERR_UNSUPPORTED beyond; the reference has no such limit, model_functions/nnls.py:37-77).  Why 256 and not
