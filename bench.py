@@ -455,6 +455,47 @@ def _gather_floats(vals, dist, device):
     return [[float(x) for x in b.cpu()] for b in bufs]
 
 
+def all_ranks_timed(call, verify, reps, n_total, world, dist, rdev, sync=lambda: None):
+    """`reps` barrier-aligned repetitions of `call()` on every rank: value = n_total / median over reps of (max over ranks of the
+    call time).  `verify(result)` -> (equals the device-resident result, bytes moved).  A failure on one rank (no host memory
+    for its result, a HIP error) must not leave the others waiting at a barrier and take the resident figures of the line with
+    it: every rank goes through the same collectives whatever happens to its calls, and the line reports the failure.
+    (tests/test_multirank_gloo.py runs this with world_size 2 on the CPU, including a rank that fails.)"""
+    err = ""
+    r = None
+    try:
+        r = call()  # warm-up: staging slab / ring slots, first-touch of the helper threads
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    locals_ = []
+    for _ in range(reps):
+        r = None  # the previous result is released before the clock starts
+        sync()
+        dist.barrier()
+        t = time.perf_counter()
+        if not err:
+            try:
+                r = call()
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+        locals_.append(time.perf_counter() - t)
+        dist.barrier()
+    same, nbytes = False, 0
+    if not err and r is not None:
+        same, nbytes = verify(r)
+    per_rank = _gather_floats(locals_ + [float(same), float(nbytes), 0.0 if err else 1.0], dist, rdev)
+    if any(pr[reps + 2] == 0.0 for pr in per_rank):
+        bad = [i for i, pr in enumerate(per_rank) if pr[reps + 2] == 0.0]
+        return {"value": None, "unit": "voxels/s", "n_gpus": world, "error": f"host-array call failed on rank(s) {bad}" + (f"; this rank: {err}" if err else "")}
+    call_s = [max(pr[i] for pr in per_rank) for i in range(reps)]  # a rep ends when its slowest rank is home
+    dt = float(np.median(call_s))
+    return {"value": n_total / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "ms_reps": [c * 1e3 for c in call_s], "steps": reps,
+            "n_gpus": world, "per_rank_ms": [[x * 1e3 for x in pr[:reps]] for pr in per_rank],
+            "per_rank_pcie_GBps": [pr[reps + 1] / float(np.median(pr[:reps])) / 1e9 for pr in per_rank],
+            "pcie_GBps": sum(pr[reps + 1] for pr in per_rank) / dt / 1e9,
+            "equals_device_resident_result": all(pr[reps] == 1.0 for pr in per_rank)}
+
+
 def host_mode_ranks(leg, dist, world, torch, n_total, reps=3):
     """SURVEY 8(d)'s metric at N ranks: every rank hands ITS shard to the C ABI as host (numpy) arrays at the same moment
     -- barrier, call, barrier -- so the ranks' uploads and downloads meet on the host's memory system as they would in a
@@ -469,44 +510,14 @@ def host_mode_ranks(leg, dist, world, torch, n_total, reps=3):
         kw = dict(max_nfev=250, ftol=1e-8, jac=leg.jac, want_pcov=leg.want_pcov, device=leg.device.index)
         call = lambda: leg.api.curvefit(leg.model, leg.b, y, leg.p0, leg.lo, leg.hi, **kw)
         ref, key = leg.popt, "popt"
-    # A failure on one rank (no host memory for its result, a HIP error) must not leave the others waiting at a barrier and take
-    # the resident figures of the line with it: every rank goes through the same collectives whatever happens to its calls.
-    err = ""
-    r = None
-    try:
-        r = call()  # warm-up: staging slab / ring slots, first-touch of the helper threads
-    except Exception as e:  # noqa: BLE001
-        err = f"{type(e).__name__}: {e}"
-    locals_ = []
-    for _ in range(reps):
-        r = None  # the previous result is released before the clock starts
-        torch.cuda.synchronize()
-        dist.barrier()
-        t = time.perf_counter()
-        if not err:
-            try:
-                r = call()
-            except Exception as e:  # noqa: BLE001
-                err = f"{type(e).__name__}: {e}"
-        locals_.append(time.perf_counter() - t)
-        dist.barrier()
-    same, nbytes = False, 0
-    if not err and r is not None:
+
+    def verify(r):
         nbytes = int(y.nbytes + sum(a.nbytes for a in r.values() if a is not None))
         m = min(65536, ref.shape[-1] if key == "popt" else ref.shape[0])
         got = torch.from_numpy(np.ascontiguousarray(r[key][..., :m] if key == "popt" else r[key][:m])).to(ref.device)
-        same = bool((got == (ref[..., :m] if key == "popt" else ref[:m])).all().item())
-    per_rank = _gather_floats(locals_ + [float(same), float(nbytes), 0.0 if err else 1.0], dist, rdev)
-    if any(pr[reps + 2] == 0.0 for pr in per_rank):
-        bad = [i for i, pr in enumerate(per_rank) if pr[reps + 2] == 0.0]
-        return {"value": None, "unit": "voxels/s", "n_gpus": world, "error": f"host-array call failed on rank(s) {bad}" + (f"; this rank: {err}" if err else "")}
-    call_s = [max(pr[i] for pr in per_rank) for i in range(reps)]  # a rep ends when its slowest rank is home
-    dt = float(np.median(call_s))
-    return {"value": n_total / dt, "unit": "voxels/s", "ms_per_step": dt * 1e3, "ms_reps": [c * 1e3 for c in call_s], "steps": reps,
-            "n_gpus": world, "per_rank_ms": [[x * 1e3 for x in pr[:reps]] for pr in per_rank],
-            "per_rank_pcie_GBps": [pr[reps + 1] / float(np.median(pr[:reps])) / 1e9 for pr in per_rank],
-            "pcie_GBps": sum(pr[reps + 1] for pr in per_rank) / dt / 1e9,
-            "equals_device_resident_result": all(pr[reps] == 1.0 for pr in per_rank)}
+        return bool((got == (ref[..., :m] if key == "popt" else ref[:m])).all().item()), nbytes
+
+    return all_ranks_timed(call, verify, reps, n_total, world, dist, rdev, sync=torch.cuda.synchronize)
 
 
 def timed(leg, steps, warmup, world, dist, torch):

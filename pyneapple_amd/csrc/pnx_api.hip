@@ -1153,6 +1153,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         PNX_HIP(hipMemcpy(where.data(), dctx.bail, where.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {  // (T) of a double rounds to nearest, as the device's narrowing copy does
             const size_t v = (size_t)where[(size_t)i];
+            if (where[(size_t)i] < 0 || v >= nv) return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[(size_t)i], nv);
             for (int j = 0; j < P.n_bins; ++j) coeff[v * P.n_bins + j] = (T)hc[(size_t)i * P.n_bins + j];
             rnorm[v] = (T)hr[(size_t)i];
             if (status) status[v] = hs[(size_t)i];
@@ -1341,6 +1342,7 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
         PNX_HIP(hipMemcpy(where.data(), dctx.bail, n * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) {
             const size_t v = (size_t)where[i];
+            if (where[i] < 0 || v >= nv) return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[i], nv);
             rnorm[v] = hr[i];
             if (status) status[v] = hs[i];
             if (iters) iters[v] = hi[i];

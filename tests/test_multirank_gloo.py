@@ -64,3 +64,63 @@ def test_two_ranks_equal_single_process(tmp_path):
         np.testing.assert_array_equal(d["popt"], ref["popt"].T)   # bit-exact: same code, same rows
         np.testing.assert_array_equal(d["status"], ref["status"])
         assert float(d["t"]) == 2.0                               # max over ranks
+
+
+def _bench_worker(rank, world, port, out_dir, fail_rank):
+    """bench.py's barrier-aligned timing of a host-array call on every rank (all_ranks_timed), with a stand-in for the call."""
+    import json
+    import sys
+    import time
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    calls = [0]
+
+    def call():
+        calls[0] += 1
+        if rank == fail_rank and calls[0] == 2:  # the warm-up works, the first timed call fails
+            raise MemoryError("no room for the result")
+        time.sleep(0.01 * (rank + 1))
+        return {"popt": np.zeros((3, 100 * (rank + 1)))}
+
+    out = bench.all_ranks_timed(call, lambda r: (True, int(r["popt"].nbytes)), 3, 1000, world, dist, "cpu")
+    with open(os.path.join(out_dir, f"b{rank}.json"), "w") as fh:
+        json.dump({"out": out, "calls": calls[0]}, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_host_leg_of_the_bench_on_two_ranks(tmp_path, fail_rank):
+    """The PCIe-inclusive leg of an N > 1 bench line: the call time of a repetition is the slowest rank's, per-rank rates come
+    back on every rank -- and a rank whose call fails is reported in the line instead of leaving its peer at a barrier."""
+    import json
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path), fail_rank), nprocs=2, join=True)
+    res = [json.load(open(tmp_path / f"b{k}.json")) for k in range(2)]
+    if fail_rank < 0:
+        for r in res:
+            o = r["out"]
+            assert o["n_gpus"] == 2 and o["steps"] == 3 and o["equals_device_resident_result"] is True
+            assert 18.0 < o["ms_per_step"] < 200.0           # the slower rank (20 ms) sets the time
+            assert o["value"] == pytest.approx(1000 / (o["ms_per_step"] * 1e-3))
+            assert len(o["per_rank_pcie_GBps"]) == 2 and min(o["per_rank_pcie_GBps"]) > 0
+            assert o["per_rank_ms"][0][0] < o["per_rank_ms"][1][0]
+        assert res[0]["out"]["ms_reps"] == res[1]["out"]["ms_reps"]   # both ranks report the same line
+    else:
+        for k, r in enumerate(res):
+            o = r["out"]
+            assert o["value"] is None and "rank(s) [1]" in o["error"]
+            assert ("MemoryError" in o["error"]) == (k == 1)
+        assert res[1]["calls"] == 2 and res[0]["calls"] == 4          # the healthy rank ran all its calls and did not hang
