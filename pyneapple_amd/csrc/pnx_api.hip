@@ -1056,6 +1056,17 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
     DevBuf dslab;
     NnlsDefer dctx{};
+    double *d_sc = nullptr, *d_sr = nullptr;
+    int8_t *d_ss = nullptr;
+    int32_t *d_si = nullptr, *d_iota = nullptr;
+    struct SideStream {  // the deferred pass runs beside the last chunk's download
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        ~SideStream() {
+            if (s) (void)hipStreamDestroy(s);
+            if (e) (void)hipEventDestroy(e);
+        }
+    } side;
     if (can_defer) {
         for (int pass = 0; pass < 2; ++pass) {
             Carver c;
@@ -1063,10 +1074,28 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
             dctx.counters = (int32_t *)c.take(2 * sizeof(int32_t));
             dctx.bail = (int32_t *)c.take(nv * sizeof(int32_t));
             dctx.y_side = (double *)c.take((size_t)defer_cap * P.n_meas * sizeof(double));
+            // results of the deferred pass, sized for the side buffer's capacity: the pass is launched behind the last chunk's
+            // solve -- before the host knows how many voxels it holds -- so that it overlaps that chunk's download
+            d_sc = (double *)c.take((size_t)defer_cap * P.n_bins * sizeof(double));
+            d_sr = (double *)c.take((size_t)defer_cap * sizeof(double));
+            d_ss = (int8_t *)c.take((size_t)defer_cap);
+            d_si = (int32_t *)c.take((size_t)defer_cap * sizeof(int32_t));
+            d_iota = (int32_t *)c.take((size_t)defer_cap * sizeof(int32_t));
             if (pass == 0 && (rc = dslab.alloc(c.off))) return rc;
         }
         dctx.cap = defer_cap;
+        std::vector<int32_t> idx((size_t)defer_cap);
+        for (int i = 0; i < defer_cap; ++i) idx[(size_t)i] = i;
+        PNX_HIP(hipMemcpy(d_iota, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        {   // lowest priority, like every kernel stream of the host paths: hardware queues are pooled per priority, and a copy
+            // must never sit in a queue behind a kernel (the download of the last chunk would wait for this pass)
+            int prio_least = 0, prio_greatest = 0;
+            PNX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            PNX_HIP(hipStreamCreateWithPriority(&side.s, hipStreamNonBlocking, prio_least));
+        }
+        PNX_HIP(hipEventCreateWithFlags(&side.e, hipEventDisableTiming));
     }
+    const bool overlap_pass = env_int("PNX_NNLS_DEFER_OVERLAP", 1, 0, 1) != 0;
     auto run = [&](const bool defer) -> int {
         if (defer) PNX_HIP(hipMemset(dctx.counters, 0, 2 * sizeof(int32_t)));
         auto span = [&](int k, size_t &off, size_t &c) {
@@ -1091,6 +1120,13 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
                 NnlsDefer d = dctx;
                 d.base = (int64_t)off;
                 r = nnls_blk_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s, &d);
+                if (!r && k == n_chunks - 1 && overlap_pass) {
+                    // every chunk has appended its handed-over voxels: ONE pass of the general kernel over the side buffer, on a
+                    // stream of its own behind this chunk's solve, while the chunk's spectra go home (8 ms of download, 9 ms of pass)
+                    PNX_HIP(hipEventRecord(side.e, s));
+                    PNX_HIP(hipStreamWaitEvent(side.s, side.e, 0));
+                    r = nnls_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+                }
             } else {
                 r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
             }
@@ -1120,30 +1156,20 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         HostCallGuard hg;
         int r = run_pipeline(n_chunks, n_slots, 1, hg.touchers(), P.device, st, ops);
         if (r || !defer) return r;
+        if (!overlap_pass) {  // PNX_NNLS_DEFER_OVERLAP=0: the pass after the ring has drained (round 3's order)
+            int rr = nnls_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+            if (rr) return rr;
+        }
+        PNX_HIP(hipStreamSynchronize(side.s));  // the deferred pass (launched behind the last chunk's solve)
         int32_t cnt[2] = {0, 0};
         PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
         const int n = cnt[0];
         if (n > defer_cap) return kDeferOverflow;  // more handed-over voxels than the side buffer holds: run again, one pass per chunk
         if (n == 0) return PNX_OK;
-        DevBuf side;
-        double *sc = nullptr, *sr = nullptr;
-        int8_t *ss = nullptr;
-        int32_t *si = nullptr, *iota = nullptr;
-        for (int pass = 0; pass < 2; ++pass) {
-            Carver c;
-            c.base = (char *)side.p;
-            sc = (double *)c.take((size_t)n * P.n_bins * sizeof(double));
-            sr = (double *)c.take((size_t)n * sizeof(double));
-            ss = (int8_t *)c.take((size_t)n);
-            si = (int32_t *)c.take((size_t)n * sizeof(int32_t));
-            iota = (int32_t *)c.take((size_t)n * sizeof(int32_t));
-            if (pass == 0 && (r = side.alloc(c.off))) return r;
-        }
-        std::vector<int32_t> idx((size_t)n), where((size_t)n), hi((size_t)n);
-        for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
-        PNX_HIP(hipMemcpy(iota, idx.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-        if ((r = nnls_redo_device(&P, n, dctx.y_side, max_iter, sc, sr, ss, si, iota, dctx.counters, st))) return r;
-        PNX_HIP(hipStreamSynchronize(st));
+        double *sc = d_sc, *sr = d_sr;
+        int8_t *ss = d_ss;
+        int32_t *si = d_si;
+        std::vector<int32_t> where((size_t)n), hi((size_t)n);
         std::vector<double> hc((size_t)n * P.n_bins), hr((size_t)n);
         std::vector<int8_t> hs((size_t)n);
         PNX_HIP(hipMemcpy(hc.data(), sc, hc.size() * sizeof(double), hipMemcpyDeviceToHost));

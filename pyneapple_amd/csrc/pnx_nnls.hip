@@ -174,7 +174,11 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
              (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
         long long vox = (long long)vq;
         if (A.redo_list) {
-            if (vq >= (unsigned long long)*A.redo_count) break;
+            {   // the list never holds more than n_vox entries the caller has room for (a deferred pass is launched with its
+                // side buffers' capacity before the count is known to the host)
+                const unsigned long long nr = (unsigned long long)*A.redo_count;
+                if (vq >= (nr < (unsigned long long)A.n_vox ? nr : (unsigned long long)A.n_vox)) break;
+            }
             vox = A.redo_list[vq];
         } else if (vq >= (unsigned long long)A.n_vox)
             break;
