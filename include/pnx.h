@@ -177,13 +177,16 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  *     solve of such a plan; up to round 3 more than 64 measurements were refused); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
  *     this library never changes the algorithm silently;
  *   - anything else (dense regularisers, 33..128 measurements): Gram form (pnx_nnls.hip).
- * n_bins <= 256 (PNX_ERR_UNSUPPORTED beyond; the reference has no such limit, model_functions/nnls.py:37-77).  Why 256 and not
- * 512: every kernel gives a lane of the wavefront that owns a voxel four bins.  At eight, the block kernel's LDS copy of the
- * basis is 32 x 514 doubles = 131 KB of a CU's 160 KB (66 KB now): two voxels in flight per CU instead of twelve, and it is 12
- * against 8 waves that measured 6.48 against 5.18 M voxels/s; the general kernel is compiled to exactly the 128 registers that
- * sixteen waves per CU allow, with 96 bytes of scratch already (hipcc 7.2, -O3), and eight bins per lane add the dual, the
- * passive flags and the row of G of four more bins (>= 24 registers): its 12-wave build measured 3.63 against 4.42 M voxels/s.
- * A 512-bin build would therefore be a separate, slower instantiation of both kernels; it is not there.
+ * n_bins <= 512 (PNX_ERR_UNSUPPORTED beyond; the reference has no such limit, model_functions/nnls.py:37-77; up to round 3 the
+ * limit was 256).  Up to 256 bins a lane of the wavefront that owns a voxel holds four bins, and every fast path is built on
+ * that: the block kernel's LDS copy of the basis (32 x 258 doubles = 66 KB; at eight bins per lane 131 KB of a CU's 160 KB, two
+ * voxels in flight per CU instead of twelve), the general kernel's 128 registers (sixteen waves per CU), the MFMA Gram step's
+ * 256-column product.  257 .. 512 bins run on SEPARATE, SLOWER instantiations with eight bins per lane (a "wide" plan): the
+ * Gram-form kernel at 256 registers (eight waves per CU, A^T y on the vector unit, no block kernel, no MFMA step) and the
+ * QR-form kernels with a wider dual.  Same algorithm, same decisions, same parity bar (reference fixtures g11_*, oracle
+ * tests); measured on the C4 signal with 32 b-values: 2.2 M voxels/s at 300 bins and 1.4 M at 512 with the order-2
+ * regulariser (8.6 M at 250: the step at 257 bins is a factor of four), 8.8 M / 7.8 M without (10.5 M at 250).
+ * pnx_nnls_aty_f64 (the MFMA step on its own) stays a 256-column layout and refuses a wide plan.
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;
 int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
@@ -205,7 +208,7 @@ int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int m
 
 /*
  * The MFMA Gram step of the NNLS path on its own: aty (n_vox, 256) = y (n_vox, n_meas) . basis (n_meas, n_bins),
- * columns >= n_bins zero (the layout the active-set kernel consumes).  Device pointers only; n_vox <= 2^20 per call.
+ * columns >= n_bins zero (the layout the active-set kernel consumes).  n_bins <= 256, n_meas <= 64 (PNX_ERR_UNSUPPORTED otherwise).  Device pointers only; n_vox <= 2^20 per call.
  * This is the batched-GEMM part of what NNLSSolver._fit_single_pixel hands to scipy.optimize.nnls per voxel
  * (nnls_solver.py:195-197: A^T y of the normal equations); exposed so that it can be timed and checked by itself.
  */

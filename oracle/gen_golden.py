@@ -8,7 +8,8 @@ Appendix B), runs the reference's own ``CurveFitSolver`` / ``NNLSSolver`` on
 seeded synthetic inputs and stores inputs + outputs as small ``.npz`` fixtures
 under ``tests/golden/``.  Only data is written; no reference source travels.
 
-Run (from any cwd):  python3 oracle/gen_golden.py
+Run (from any cwd):  python3 oracle/gen_golden.py            (batches g1-g9)
+                     python3 oracle/gen_golden.py g10 | g11   (later batches, each with its own seed)
 """
 from __future__ import annotations
 
@@ -455,6 +456,44 @@ def main_g10():
         print(f"g10_segmentationwise{tag}: labels={fit.segment_labels} names={names}")
 
 
+def main_g11():
+    """Sixth batch (round 4): spectra with more than 256 bins -- the reference takes any n_bins (models/nnls.py:37-77); the HIP
+    library runs them on its eight-bins-per-lane instantiations (include/pnx.h) -- and the spectrum post-processing on them."""
+    from pyneapple.utility.spectrum import apply_cutoffs, find_spectrum_peaks
+
+    rng = np.random.default_rng(SEED + 11)
+    gen_nnls("g11_nnls_300_r2", (0.0008, 0.5), 300, 2, 0.02, 32, 32, rng)
+    gen_nnls("g11_nnls_512_r2", (0.0008, 0.5), 512, 2, 0.02, 32, 16, rng)
+    gen_nnls("g11_nnls_350_r1", (0.0008, 0.5), 350, 1, 0.02, 24, 16, rng)
+    gen_nnls("g11_nnls_300_r3", (0.0008, 0.5), 300, 3, 0.02, 32, 16, rng)
+    gen_nnls("g11_nnls_400_r0", (0.0008, 0.5), 400, 0, 0.02, 32, 32, rng)
+    gen_nnls("g11_nnls_300_r2_maxiter20", (0.0008, 0.5), 300, 2, 0.02, 32, 16, rng, max_iter=20)
+    MAXP = 8
+    cutoffs = [(0.0008, 0.003), (0.003, 0.02), (0.02, 0.5)]
+    for src, regularized in (("g11_nnls_300_r2", True), ("g11_nnls_512_r2", True), ("g11_nnls_400_r0", False)):
+        d = np.load(os.path.join(OUT, src + ".npz"))
+        spec, bins = d["coefficients"], d["bins"]
+        nv = spec.shape[0]
+        for height in (0.1, 5.0):
+            n_peaks = np.zeros(nv, dtype=np.int32)
+            dv = np.full((nv, MAXP), np.nan)
+            fv = np.full((nv, MAXP), np.nan)
+            dc = np.full((nv, len(cutoffs)), np.nan)
+            fc = np.full((nv, len(cutoffs)), np.nan)
+            for i in range(nv):
+                dd, ff = find_spectrum_peaks(spec[i], bins, height=height, regularized=regularized)
+                assert len(dd) <= MAXP
+                n_peaks[i] = len(dd)
+                dv[i, :len(dd)] = dd
+                fv[i, :len(dd)] = ff
+                dc[i], fc[i] = apply_cutoffs(dd, ff, cutoffs)
+            name = f"g11_spectrum_{src[4:]}_h{height:g}".replace(".", "p")
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), spectrum=spec, bins=bins, height=height,
+                                regularized=np.array(regularized), n_peaks=n_peaks, d_values=dv, f_values=fv,
+                                cutoffs=np.array(cutoffs), d_cut=dc, f_cut=fc, **_versions())
+            print(f"{name}: peaks/voxel mean {n_peaks.mean():.2f} max {n_peaks.max()}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
@@ -475,6 +514,13 @@ if __name__ == "__main__":
         sys.path.insert(0, REF_SRC)
         _install_shims()
         main_g10()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g11":
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        os.makedirs(OUT, exist_ok=True)
+        main_g11()
     elif len(sys.argv) > 1 and sys.argv[1] == "g8":
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
         sys.dont_write_bytecode = True

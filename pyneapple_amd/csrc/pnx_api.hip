@@ -934,7 +934,7 @@ int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const dou
                          int n_reg, int device) {
     if (!plan || !basis) return set_error(PNX_ERR_INVALID, "NULL pointer");
     if (n_meas < 1 || n_bins < 1 || n_reg < 0 || (n_reg && !reg)) return set_error(PNX_ERR_INVALID, "bad NNLS sizes");
-    if (n_bins > kNnlsMaxBins) return set_error(PNX_ERR_UNSUPPORTED, "n_bins=%d > %d", n_bins, kNnlsMaxBins);
+    if (n_bins > kNnlsWideBins) return set_error(PNX_ERR_UNSUPPORTED, "n_bins=%d > %d", n_bins, kNnlsWideBins);
     if (n_meas > kNnlsMaxMeas) return set_error(PNX_ERR_UNSUPPORTED, "n_meas=%d > %d", n_meas, kNnlsMaxMeas);
     DeviceInfo *dev;
     int rc = get_device(device, &dev);

@@ -46,7 +46,7 @@ namespace pnx {
 #endif
 constexpr int kLdsRows = PNX_NNLS_LDS_ROWS;  // rows of M kept in LDS (<= 64)
 constexpr int kLdsTri = kLdsRows * (kLdsRows + 1) / 2;
-constexpr int kGlobTri = kNnlsMaxBins * (kNnlsMaxBins + 1) / 2 - kLdsTri;  // doubles of overflow scratch per wave
+template <int KS> constexpr int glob_tri() { return (kW * KS) * (kW * KS + 1) / 2 - kLdsTri; }  // doubles of overflow scratch per wave
 // Row access that is "LDS or slab" by a (uniform or per-lane) row index.  Typed by address space: with plain pointers the compiler
 // folds the two cases into ONE flat access through a selected base pointer, and a flat access waits for both the LDS and the
 // vector-memory counter (round 4, found in the block kernel first: pnx_nnls_blk.hip; 15 flat accesses here: + 5-7 %).
@@ -80,11 +80,11 @@ __device__ inline int tri(int i) { return i * (i + 1) / 2; }
 
 // out[s] (k = lane + 64 s) = sum_{i >= k} va_i * M[i][k]  (and the same with vb when TWO): one sweep over the
 // packed lower-triangular M, every row read contiguously; va_i / vb_i are broadcast with v_readlane.
-template <bool TWO>
-__device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int lane, const double (&va)[kSlots],
-                                const double (&vb)[kSlots], double (&oa)[kSlots], double (&ob)[kSlots]) {
+template <bool TWO, int KS>
+__device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int lane, const double (&va)[KS],
+                                const double (&vb)[KS], double (&oa)[KS], double (&ob)[KS]) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < KS; ++s) {
         oa[s] = 0;
         ob[s] = 0;
     }
@@ -143,7 +143,7 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
             }
         }
     };
-    for_pos4(kLdsRows, p, four, one);
+    for_pos4n<KS>(kLdsRows, p, four, one);
 }
 
 
@@ -153,7 +153,10 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #define STAMP(k) do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const NnlsArgs A) {
+// KS: bins (and passive-set positions) per lane -- 4 up to 256 bins, 8 for the wide plans (257 .. 512 bins: twice the position-
+// and bin-indexed registers, two waves per SIMD instead of four, A^T y on the VALU)
+template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES_PER_SIMD : 2) nnls_kernel(const NnlsArgs A) {
+    constexpr int kBS = kW * KS;  // row stride of G, Bp (and of the MFMA product, KS == 4 only)
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
     extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M, then bc[64]
     double *bc = Mlds + kLdsTri;      // broadcast buffer: position-indexed values of slot 0, read with a uniform address
     const int lane = threadIdx.x;
-    double *Mg = A.Mglob + (size_t)blockIdx.x * kGlobTri;
+    double *Mg = A.Mglob + (size_t)blockIdx.x * glob_tri<KS>();
     gen_lds_double *MldsT = (gen_lds_double *)Mlds;
     gen_glb_double *MgT = (gen_glb_double *)Mg;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
@@ -199,10 +202,10 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
         }
         yn2 = wave_sum(yn2);
         finite = __all(finite ? 1 : 0) != 0;
-        double aty[kSlots] = {0, 0, 0, 0}, w[kSlots], z[kSlots] = {0, 0, 0, 0};
-        bool inP[kSlots] = {false, false, false, false};
-        if (finite && A.aty) {
-            const double *ar = A.aty + (size_t)vox * kNnlsMaxBins + 2 * lane;
+        double aty[KS] = {}, w[KS], z[KS] = {};
+        bool inP[KS] = {};
+        if (KS == 4 && finite && A.aty) {
+            const double *ar = A.aty + (size_t)vox * kBS + 2 * lane;
             const double2 a0 = *reinterpret_cast<const double2 *>(ar);
             const double2 a1 = *reinterpret_cast<const double2 *>(ar + 128);
             aty[0] = a0.x;
@@ -213,54 +216,57 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
 #pragma unroll 4
             for (int k = 0; k < nm; ++k) {
                 const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
-                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
-                const double2 b0 = *reinterpret_cast<const double2 *>(br);
-                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
-                aty[0] += b0.x * yk;
-                aty[1] += b0.y * yk;
-                aty[2] += b1.x * yk;
-                aty[3] += b1.y * yk;
+                const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
+                double2 bh[KS / 2];
+#pragma unroll
+                for (int h = 0; h < KS / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+#pragma unroll
+                for (int h = 0; h < KS / 2; ++h) {
+                    aty[2 * h] += bh[h].x * yk;
+                    aty[2 * h + 1] += bh[h].y * yk;
+                }
             }
         }
         // position-indexed state
-        double q[kSlots] = {0, 0, 0, 0}, x[kSlots] = {0, 0, 0, 0};
-        int pidx[kSlots] = {0, 0, 0, 0};
+        double q[KS] = {}, x[KS] = {};
+        int pidx[KS] = {};
         int p = 0, iteration = 0, status = finite ? 1 : -2;
         STAMP(0);
 
         while (status == 1 && p < n && p < m_total) {
             // ---- dual w = A^T y - G[:,P] x_P on the zero set: p rows of G (L2 resident), kGBatch in flight
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) w[s] = aty[s];
+            for (int s = 0; s < KS; ++s) w[s] = aty[s];
             // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
             // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
             bc[lane] = x[0];  // the kernel is VALU-issue bound: x_pos comes back through an LDS broadcast read, not 2 readlanes
 #pragma unroll
-            for (int sl = 0; sl < kSlots; ++sl) {
+            for (int sl = 0; sl < KS; ++sl) {
                 if (p <= sl * kW) break;  // wave-uniform
                 const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
                 int l0 = 0;
                 for (; l0 + kGBatch <= cnt; l0 += kGBatch) {  // full batches: no clamping, no masking
-                    double2 ga[kGBatch], gb[kGBatch];
+                    double2 gg[kGBatch][KS / 2];
                     double xs[kGBatch];
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
                         const int col = __builtin_amdgcn_readlane(pidx[sl], l0 + u);
                         xs[u] = sl == 0 ? bc[l0 + u] : rl(x[sl], l0 + u);
-                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
-                        ga[u] = *reinterpret_cast<const double2 *>(gc);
-                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                        const double *gc = A.G + (size_t)col * kBS + 2 * lane;
+#pragma unroll
+                        for (int h = 0; h < KS / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
                     }
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
-                        w[0] -= ga[u].x * xs[u];
-                        w[1] -= ga[u].y * xs[u];
-                        w[2] -= gb[u].x * xs[u];
-                        w[3] -= gb[u].y * xs[u];
+#pragma unroll
+                        for (int h = 0; h < KS / 2; ++h) {
+                            w[2 * h] -= gg[u][h].x * xs[u];
+                            w[2 * h + 1] -= gg[u][h].y * xs[u];
+                        }
                     }
                 }
                 if (l0 < cnt) {  // ragged last batch
-                    double2 ga[kGBatch], gb[kGBatch];
+                    double2 gg[kGBatch][KS / 2];
                     double xs[kGBatch];
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
@@ -269,54 +275,57 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                         const int col = __builtin_amdgcn_readlane(pidx[sl], ll_);
                         const double xv = rl(x[sl], ll_);
                         xs[u] = on ? xv : 0.0;
-                        const double *gc = A.G + (size_t)col * kNnlsMaxBins + 2 * lane;
-                        ga[u] = *reinterpret_cast<const double2 *>(gc);
-                        gb[u] = *reinterpret_cast<const double2 *>(gc + 128);
+                        const double *gc = A.G + (size_t)col * kBS + 2 * lane;
+#pragma unroll
+                        for (int h = 0; h < KS / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
                     }
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
-                        w[0] -= ga[u].x * xs[u];
-                        w[1] -= ga[u].y * xs[u];
-                        w[2] -= gb[u].x * xs[u];
-                        w[3] -= gb[u].y * xs[u];
+#pragma unroll
+                        for (int h = 0; h < KS / 2; ++h) {
+                            w[2 * h] -= gg[u][h].x * xs[u];
+                            w[2 * h + 1] -= gg[u][h].y * xs[u];
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s)
+            for (int s = 0; s < KS; ++s)
                 if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
             STAMP(1);
 
             bool accepted = false;
             int jmax = 0;
             double lam = 0, qn = 0, inv_lam = 0;
-            double l[kSlots];
+            double l[KS];
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
                 double best = -INFINITY;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) best = fmax(best, w[s]);
+                for (int s = 0; s < KS; ++s) best = fmax(best, w[s]);
                 best = wave_max(best);
                 if (!(best > 0)) break;  // KKT satisfied
                 int bj = kNone;
 #pragma unroll
-                for (int s = kSlots - 1; s >= 0; --s)
+                for (int s = KS - 1; s >= 0; --s)
                     if (w[s] == best) bj = binof(lane, s);
                 jmax = wave_min_i(bj);
                 // ---- g = G[P, jmax] (by position), l = M g
-                const double *grow = A.G + (size_t)jmax * kNnlsMaxBins;
-                double g[kSlots];
+                const double *grow = A.G + (size_t)jmax * kBS;
+                double g[KS];
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) g[s] = (lane + kW * s < p) ? grow[pidx[s]] : 0.0;
+                for (int s = 0; s < KS; ++s) g[s] = (lane + kW * s < p) ? grow[pidx[s]] : 0.0;
                 const double Gjj = grow[jmax];
                 double atyj;
                 {
                     const int ol = (jmax & 127) >> 1, os = ((jmax >> 7) << 1) | (jmax & 1);  // owner lane / slot
-                    const double av = os == 0 ? aty[0] : (os == 1 ? aty[1] : (os == 2 ? aty[2] : aty[3]));
+                    double av = aty[KS - 1];
+#pragma unroll
+                    for (int s = KS - 2; s >= 0; --s) av = os == s ? aty[s] : av;
                     atyj = rl(av, ol);
                 }
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) l[s] = 0;
+                for (int s = 0; s < KS; ++s) l[s] = 0;
                 {
                     // LDS rows as a column sweep: uniform k, lane i accumulates M[i][k] g_k for i >= k
                     const int plim = p < kLdsRows ? p : kLdsRows;
@@ -384,11 +393,11 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                             if (lane == ((i + r) & 63)) l[si] = li;
                         }
                     };
-                    for_pos4(kLdsRows, p, four, one);
+                    for_pos4n<KS>(kLdsRows, p, four, one);
                 }
                 double ll = 0, lq = 0;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     if (lane + kW * s < p) {
                         ll += l[s] * l[s];
                         lq += l[s] * q[s];
@@ -417,7 +426,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 }
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KS; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;
             }
             STAMP(2);
@@ -431,11 +440,11 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 // one sweep over M gives the new row r = -(l^T M) / lam.  z = M^T q is then a rank-one update of the
                 // current solution (x == z = M_old^T q_old whenever a column enters): z_k = x_k + r_k * qn.  After
                 // every removal z is recomputed from scratch (second sweep below), so nothing drifts.
-                double a1[kSlots], a2[kSlots];
-                col_pass<false>(Mlds, Mg, p, lane, l, l, a1, a2);
+                double a1[KS], a2[KS];
+                col_pass<false, KS>(Mlds, Mg, p, lane, l, l, a1, a2);
                 const double inv = inv_lam;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     const int k = lane + kW * s;
                     if (k <= p) {
                         const double r = k < p ? -a1[s] * inv : inv;
@@ -467,10 +476,10 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     // divisions and two wave reductions
                     bool viol = false;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) viol = viol || (lane + kW * s < p && z[s] <= 0);
+                    for (int s = 0; s < KS; ++s) viol = viol || (lane + kW * s < p && z[s] <= 0);
                     if (!__any(viol ? 1 : 0)) {
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s)
+                        for (int s = 0; s < KS; ++s)
                             if (lane + kW * s < p) x[s] = z[s];
                         break;
                     }
@@ -478,7 +487,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 double bestT = INFINITY;
                 int bpos = kNone;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
+                for (int s = 0; s < KS; ++s) {
                     const int i = lane + kW * s;
                     if (i < p && z[s] <= 0) {
                         const double T = -x[s] / (z[s] - x[s]);
@@ -496,13 +505,13 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 }
                 if (bpos == kNone) {
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s)
+                    for (int s = 0; s < KS; ++s)
                         if (lane + kW * s < p) x[s] = z[s];
                     break;
                 }
                 const double alpha = bestT;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KS; ++s)
                     if (lane + kW * s < p) x[s] = x[s] + alpha * (z[s] - x[s]);
                 STAMP(4);
                 int jj = bpos;
@@ -512,10 +521,10 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
 #endif
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-                    double mv[kSlots], pre[kSlots];
+                    double mv[KS], pre[KS];
                     double carry = 0;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
+                    for (int s = 0; s < KS; ++s) {
                         const int i = lane + kW * s;
                         mv[s] = 0;
                         pre[s] = carry;
@@ -531,12 +540,12 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                             carry += rl(sc, 63);
                         }
                     }
-                    double mnext[kSlots], prenext[kSlots];
+                    double mnext[KS], prenext[KS];
                     shift_down(mv, mnext, lane);
                     shift_down(pre, prenext, lane);
-                    double cs[kSlots], sn[kSlots];
+                    double cs[KS], sn[KS];
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) {
+                    for (int s = 0; s < KS; ++s) {
                         const int i = lane + kW * s;
                         cs[s] = 1.0;
                         sn[s] = 0.0;
@@ -550,14 +559,11 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                             }
                         }
                     }
-                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(pidx[0], jj & 63)
-                                      : jj < 2 * kW ? __builtin_amdgcn_readlane(pidx[1], jj & 63)
-                                      : jj < 3 * kW ? __builtin_amdgcn_readlane(pidx[2], jj & 63)
-                                                    : __builtin_amdgcn_readlane(pidx[3], jj & 63);
+                    const int bin_out = get_at_i(pidx, jj);
                     {
-                        double car[kSlots];
+                        double car[KS];
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) {
+                        for (int s = 0; s < KS; ++s) {
                             const int c = lane + kW * s;
                             car[s] = 0.0;
                             if (c < jj) {
@@ -567,11 +573,10 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                                     car[s] = MgT[tri(jj) - kLdsTri + c];
                             }
                         }
-                        double carq = jj < kW ? rl(q[0], jj & 63) : jj < 2 * kW ? rl(q[1], jj & 63)
-                                    : jj < 3 * kW ? rl(q[2], jj & 63) : rl(q[3], jj & 63);
-                        double qsh[kSlots];
+                        double carq = get_at(q, jj);
+                        double qsh[KS];
                         shift_down(q, qsh, lane);  // qsh[i] = q[i + 1]
-                        for_pos<2>(jj, p - 1, [&](int i, auto S) {
+                        for_posn<KS, 2>(jj, p - 1, [&](int i, auto S) {
                             constexpr int si = decltype(S)::value;
                             const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
                             const double qnx = rl(qsh[si], i & 63);
@@ -600,12 +605,12 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     }
                     // ---- drop position jj from x / pidx
                     {
-                        double xsh[kSlots];
-                        int psh[kSlots];
+                        double xsh[KS];
+                        int psh[KS];
                         shift_down(x, xsh, lane);
                         shift_down_i(pidx, psh, lane);
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) {
+                        for (int s = 0; s < KS; ++s) {
                             const int i = lane + kW * s;
                             if (i >= jj && i < p - 1) {
                                 x[s] = xsh[s];
@@ -619,7 +624,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
-                    for (int s = kSlots - 1; s >= 0; --s) {
+                    for (int s = KS - 1; s >= 0; --s) {
                         const int i = lane + kW * s;
                         if (i < p && x[s] <= 0) bad = i;
                     }
@@ -630,8 +635,8 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 STAMP(5);
                 // ---- z = M^T q
                 {
-                    double dummy[kSlots];
-                    col_pass<false>(Mlds, Mg, p, lane, q, q, z, dummy);
+                    double dummy[KS];
+                    col_pass<false, KS>(Mlds, Mg, p, lane, q, q, z, dummy);
                 }
                 STAMP(6);
             }
@@ -642,22 +647,29 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
         // the bin-ordered scratch that turns x by position into x by bin (one scatter instead of p x 14 select instructions)
         // and, for the reference's banded regularisers, carries the stencil R x (the generic loop over rows of RT is p
         // dependent L2 round trips per 64 rows of R: 110 k cycles per voxel, 6 % of the kernel, measured with the stamps)
-        double xb[kSlots] = {0, 0, 0, 0};
+        double xb[KS] = {};
         double rn;
         if (status == 1) {
             wave_sync();
-            double *xbuf = Mlds;  // [2 + 256 + 2] <= kLdsTri
-            double tt = 0, dummy[kSlots];
+            double *xbuf = Mlds;  // [2 + 64 KS + 2] <= kLdsTri
+            double tt = 0, dummy[KS];
             reg_terms<false>(xbuf, A.rc, A.rhb, A.rhb ? nreg : 0, p, lane, x, pidx, dummy, &tt);  // leaves x in bin order in xbuf
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) xb[s] = xbuf[2 + binof(lane, s)];
+            for (int s = 0; s < KS; ++s) xb[s] = xbuf[2 + binof(lane, s)];
             wave_sync();
             double acc = 0;
             for (int k = 0; k < nm; ++k) {
-                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
-                const double2 b0 = *reinterpret_cast<const double2 *>(br);
-                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
-                const double fit = wave_sum(b0.x * xb[0] + b0.y * xb[1] + b1.x * xb[2] + b1.y * xb[3]);
+                const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
+                double2 bh[KS / 2];
+#pragma unroll
+                for (int h = 0; h < KS / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+                double part = bh[0].x * xb[0] + bh[0].y * xb[1];
+#pragma unroll
+                for (int h = 1; h < KS / 2; ++h) {
+                    part += bh[h].x * xb[2 * h];
+                    part += bh[h].y * xb[2 * h + 1];
+                }
+                const double fit = wave_sum(part);
                 const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
                 if (lane == 0) acc += (fit - yk) * (fit - yk);
             }
@@ -667,7 +679,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
                 for (int i0 = 0; i0 < nreg; i0 += kW) {
                     const int i = i0 + lane;
                     double r = 0;
-                    for_pos<4>(0, p, [&](int pos, auto S) {
+                    for_posn<KS, 4>(0, p, [&](int pos, auto S) {
                         constexpr int si = decltype(S)::value;
                         const int b = __builtin_amdgcn_readlane(pidx[si], pos & 63);
                         const double xv = rl(x[si], pos & 63);
@@ -681,7 +693,7 @@ __global__ void __launch_bounds__(64, PNX_NNLS_WAVES_PER_SIMD) nnls_kernel(const
             rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
         double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const int j = binof(lane, s);
             if (j < n) cv[j] = xb[s];
         }
@@ -767,14 +779,14 @@ __global__ void __launch_bounds__(kAtyWaves * 64) nnls_aty_mfma_kernel(const dou
 
 // ---- plan-time kernels ------------------------------------------------------------------------
 // G = B^T B + reg^T reg in fp64 (one-off, 2*n^2*(n_meas+n_reg) flop = 35 MFLOP for 250 bins).
-__global__ void gram_kernel(const double *B, const double *RT, int nm, int n, int nreg, double *G) {
+__global__ void gram_kernel(const double *B, const double *RT, int nm, int n, int nreg, double *G, int gstride) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= n || i >= n) return;
     double acc = 0;
     for (int k = 0; k < nm; ++k) acc += B[(size_t)k * n + i] * B[(size_t)k * n + j];
     for (int r = 0; r < nreg; ++r) acc += RT[(size_t)i * nreg + r] * RT[(size_t)j * nreg + r];
-    G[(size_t)i * kNnlsMaxBins + j] = acc;
+    G[(size_t)i * gstride + j] = acc;
 }
 
 __global__ void basis_kernel(const double *b, const double *bins, int nm, int n, double *out) {
@@ -795,7 +807,7 @@ static size_t nnls_lds_bytes() {
     static const size_t pad = getenv("PNX_NNLS_LDS_PAD") ? (size_t)atoi(getenv("PNX_NNLS_LDS_PAD")) : 0;  // occupancy experiments
     return sizeof(double) * (kLdsTri + kW) + pad;
 }
-static_assert(kLdsTri >= 2 + kNnlsMaxBins + 2, "the epilogue's bin-ordered scratch aliases the LDS rows of M");
+static_assert(kLdsTri >= 2 + kNnlsWideBins + 2, "the epilogue's bin-ordered scratch aliases the LDS rows of M");
 
 // Is reg what model_functions/nnls.py:46-85 builds for orders 1-3: square, R[i][j] = c[j - i] inside a band of half width
 // <= 2 and exactly zero outside?  Then the regulariser is five numbers and the fast kernel applies it as a stencil.
@@ -832,18 +844,23 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
         // number of b-values (nnls_solver.py:37, 88-127)
         P->qr = zero && !getenv("PNX_NNLS_NO_QR");
     }
-    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (size_t)(kNnlsMaxBins + 1) * kNnlsMaxBins;  // one row more: the block kernel gathers column 256 (its padding bin) of a row
+    // more than 256 bins: the wide instantiations (eight bins per lane) of this file's kernel and of the QR-form kernels; no block
+    // kernel (its LDS copy of the basis would leave room for two voxels per CU), no MFMA Gram step (A^T y on the VALU)
+    const bool wide = n_bins > kNnlsMaxBins;
+    P->bstride = wide ? kNnlsWideBins : kNnlsMaxBins;
+    const size_t bs = (size_t)P->bstride;
+    const size_t nb = (size_t)n_meas * n_bins, nr = (size_t)n_reg * n_bins, ng = (bs + 1) * bs;  // one row more: the block kernel gathers column 256 (its padding bin) of a row
     for (size_t i = 0; i < nb; ++i)
         if (!std::isfinite(basis[i])) return set_error(PNX_ERR_INVALID, "basis contains non-finite values");
     PNX_HIPN(hipMalloc(&P->B, nb * sizeof(double)));
-    PNX_HIPN(hipMalloc(&P->Bp, (size_t)n_meas * kNnlsMaxBins * sizeof(double)));
-    PNX_HIPN(hipMemset(P->Bp, 0, (size_t)n_meas * kNnlsMaxBins * sizeof(double)));
+    PNX_HIPN(hipMalloc(&P->Bp, (size_t)n_meas * bs * sizeof(double)));
+    PNX_HIPN(hipMemset(P->Bp, 0, (size_t)n_meas * bs * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->RT, (nr ? nr : 1) * sizeof(double)));
     PNX_HIPN(hipMalloc(&P->G, ng * sizeof(double)));
-    PNX_HIPN(hipMemset(P->G, 0, ng * sizeof(double)));  // rows padded to 256 columns
+    PNX_HIPN(hipMemset(P->G, 0, ng * sizeof(double)));  // rows padded to bstride columns
     PNX_HIPN(hipMalloc(&P->queue, sizeof(unsigned long long)));
     PNX_HIPN(hipMemcpy(P->B, basis, nb * sizeof(double), hipMemcpyHostToDevice));
-    PNX_HIPN(hipMemcpy2D(P->Bp, kNnlsMaxBins * sizeof(double), basis, (size_t)n_bins * sizeof(double), (size_t)n_bins * sizeof(double), n_meas, hipMemcpyHostToDevice));
+    PNX_HIPN(hipMemcpy2D(P->Bp, bs * sizeof(double), basis, (size_t)n_bins * sizeof(double), (size_t)n_bins * sizeof(double), n_meas, hipMemcpyHostToDevice));
     if (nr) {
         std::vector<double> rt(nr);
         for (int i = 0; i < n_reg; ++i)
@@ -855,25 +872,31 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
         PNX_HIPN(hipMemcpy(P->RT, rt.data(), nr * sizeof(double), hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(gram_kernel, dim3((n_bins + 63) / 64, n_bins), dim3(64), 0, 0, P->B, P->RT, n_meas, n_bins,
-                       n_reg, P->G);
+                       n_reg, P->G, P->bstride);
     PNX_HIPN(hipGetLastError());
-    if (!P->qr && nnls_blk_applicable(P)) {
+    if (!P->qr && !wide && nnls_blk_applicable(P)) {
         P->blk = true;
         const int rc_ = nnls_blk_plan_init(P);
         if (rc_ != PNX_OK) return rc_;
     }
     // persistent grid: as many single-wave workgroups as fit (LDS bound), one scratch slab each
-    PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
     int occ = 0;
-    PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel, kW, nnls_lds_bytes()));
+    if (wide) {
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<8>, kW, nnls_lds_bytes()));
+    } else {
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<4>, kW, nnls_lds_bytes()));
+    }
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
     P->n_waves = occ * cus;
-    P->mglob_stride = kGlobTri;
+    P->mglob_stride = wide ? glob_tri<8>() : glob_tri<4>();  // 256 KB / 1 MB per resident wave
     // a block-kernel plan runs this kernel only on the voxels handed over (a quarter of the grid, A^T y on the VALU): a quarter
     // of the slabs, and no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
     if (P->blk) P->n_waves = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
-    PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * kGlobTri * sizeof(double)));
-    P->mfma_ok = !getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64;  // LDS stage of Bp: n_meas * 2 KiB
+    if (P->qr) P->n_waves = 1;  // a QR-form plan never launches this kernel
+    PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * P->mglob_stride * sizeof(double)));
+    P->mfma_ok = !getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64 && !wide;  // LDS stage of Bp: n_meas * 2 KiB
     if (P->mfma_ok) {
         if (!P->blk) PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
         PNX_HIPN(hipFuncSetAttribute((const void *)nnls_aty_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -938,7 +961,10 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
         }
         PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
         long long grid = c < P->n_waves ? c : P->n_waves;
-        hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+        if (P->bstride == kNnlsWideBins)
+            hipLaunchKernelGGL(nnls_kernel<8>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+        else
+            hipLaunchKernelGGL(nnls_kernel<4>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
         PNX_HIPN(hipGetLastError());
     }
     return PNX_OK;
@@ -971,7 +997,7 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
     // the plan's (quartered) persistent grid: with an empty list a wave costs one queue pull
     long long grid = P->n_waves;
     if (grid > n_vox) grid = n_vox;
-    hipLaunchKernelGGL(nnls_kernel, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(nnls_kernel<4>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);  // block-kernel plans only: never wide
     PNX_HIPN(hipGetLastError());
     return PNX_OK;
 }

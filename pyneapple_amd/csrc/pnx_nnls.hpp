@@ -7,7 +7,8 @@ namespace pnx {
 constexpr int64_t kAtyChunk = 1 << 20;  // voxels per MFMA Gram step / active-set launch pair
 
 
-constexpr int kNnlsMaxBins = 256;  // 4 bins per lane
+constexpr int kNnlsMaxBins = 256;   // 4 bins per lane: every fast path (block kernel, MFMA Gram step, 16 waves per CU)
+constexpr int kNnlsWideBins = 512;  // 8 bins per lane: the wide instantiations of the Gram- and QR-form kernels (257 .. 512 bins)
 constexpr int kNnlsMaxMeas = 128;
 
 struct NnlsPlanData {
@@ -15,9 +16,10 @@ struct NnlsPlanData {
     int cus = 0;
     int n_meas = 0, n_bins = 0, n_reg = 0;
     double *B = nullptr;      // (n_meas, n_bins) row-major: basis
-    double *Bp = nullptr;     // (n_meas, 256) zero padded copy (16-byte aligned rows for the kernel)
+    double *Bp = nullptr;     // (n_meas, bstride) zero padded copy (16-byte aligned rows for the kernel)
+    int bstride = kNnlsMaxBins;  // row stride of Bp and G: 256, or 512 for a wide plan (n_bins > 256)
     double *RT = nullptr;     // (n_bins, n_reg)  row-major: reg transposed (column j of reg contiguous)
-    double *G = nullptr;      // (n_bins, n_bins): A^T A = B^T B + reg^T reg, fp64
+    double *G = nullptr;      // (n_bins + 1, bstride): A^T A = B^T B + reg^T reg, fp64, zero padded
     double *aty = nullptr;    // (chunk, 256) A^T y of the current chunk (MFMA Gram step), null = VALU path
     double *Mglob = nullptr;  // per-wave overflow rows (>= 64) of the inverse Cholesky factor
     size_t mglob_stride = 0;  // doubles per wave

@@ -10,7 +10,7 @@
 namespace pnx {
 
 constexpr int kW = 64;
-constexpr int kSlots = kNnlsMaxBins / kW;  // 4
+constexpr int kSlots = kNnlsMaxBins / kW;  // 4 (the wide instantiations of the Gram- and QR-form kernels: kNnlsWideBins / kW = 8)
 constexpr int kNone = 1 << 30;
 
 // ---- cross-lane primitives ----------------------------------------------------------------------
@@ -97,7 +97,8 @@ __device__ inline void wave_sync() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1}: one row of G or B is two 16-byte loads per lane.
+// Bin ownership: lane l holds bins {2l, 2l+1, 128+2l, 128+2l+1} (and 256+2l, ... with eight bins per lane): one row of G or B is
+// two (four) 16-byte loads per lane.
 __device__ inline int binof(int lane, int s) { return ((s >> 1) << 7) + 2 * lane + (s & 1); }
 
 // ---- position-indexed register vectors (position i lives in lane i & 63, slot i >> 6) --------------
@@ -109,12 +110,15 @@ template <int S, int UNROLL, class F> __device__ inline void pos_range(int lo, i
 #pragma unroll UNROLL
     for (int i = a; i < b; ++i) f(i, SlotTag<S>{});
 }
-template <int UNROLL, class F> __device__ inline void for_pos(int lo, int hi, F &&f) {
-    pos_range<0, UNROLL>(lo, hi, f);
-    if (hi > kW) pos_range<1, UNROLL>(lo, hi, f);
-    if (hi > 2 * kW) pos_range<2, UNROLL>(lo, hi, f);
-    if (hi > 3 * kW) pos_range<3, UNROLL>(lo, hi, f);
+template <int S, int NS, int UNROLL, class F> __device__ inline void for_pos_from(int lo, int hi, F &&f) {
+    pos_range<S, UNROLL>(lo, hi, f);
+    if constexpr (S + 1 < NS) {
+        if (hi > (S + 1) * kW) for_pos_from<S + 1, NS, UNROLL>(lo, hi, f);
+    }
 }
+// vectors of NS slots (positions < 64 NS)
+template <int NS, int UNROLL, class F> __device__ inline void for_posn(int lo, int hi, F &&f) { for_pos_from<0, NS, UNROLL>(lo, hi, f); }
+template <int UNROLL, class F> __device__ inline void for_pos(int lo, int hi, F &&f) { for_pos_from<0, kSlots, UNROLL>(lo, hi, f); }
 // the same in groups of four: f4(i, SlotTag<S>) covers positions i .. i + 3 (all in slot S), f1 the ragged rest.  Loops
 // around v_readlane / DPP are never unrolled by the compiler, so "several rows in flight" has to be spelled out.
 template <int S, class F4, class F1> __device__ inline void pos_range4(int lo, int hi, F4 &&f4, F1 &&f1) {
@@ -124,24 +128,31 @@ template <int S, class F4, class F1> __device__ inline void pos_range4(int lo, i
     for (; i + 4 <= b; i += 4) f4(i, SlotTag<S>{});
     for (; i < b; ++i) f1(i, SlotTag<S>{});
 }
-// the same for vectors of NS slots (positions < 64 NS)
-template <int NS, class F4, class F1> __device__ inline void for_pos4n(int lo, int hi, F4 &&f4, F1 &&f1) {
-    pos_range4<0>(lo, hi, f4, f1);
-    if constexpr (NS > 1) {
-        if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
-    }
-    if constexpr (NS > 2) {
-        if (hi > 2 * kW) pos_range4<2>(lo, hi, f4, f1);
-    }
-    if constexpr (NS > 3) {
-        if (hi > 3 * kW) pos_range4<3>(lo, hi, f4, f1);
+template <int S, int NS, class F4, class F1> __device__ inline void for_pos4_from(int lo, int hi, F4 &&f4, F1 &&f1) {
+    pos_range4<S>(lo, hi, f4, f1);
+    if constexpr (S + 1 < NS) {
+        if (hi > (S + 1) * kW) for_pos4_from<S + 1, NS>(lo, hi, f4, f1);
     }
 }
-template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4 &&f4, F1 &&f1) {
-    pos_range4<0>(lo, hi, f4, f1);
-    if (hi > kW) pos_range4<1>(lo, hi, f4, f1);
-    if (hi > 2 * kW) pos_range4<2>(lo, hi, f4, f1);
-    if (hi > 3 * kW) pos_range4<3>(lo, hi, f4, f1);
+// the same for vectors of NS slots (positions < 64 NS)
+template <int NS, class F4, class F1> __device__ inline void for_pos4n(int lo, int hi, F4 &&f4, F1 &&f1) {
+    for_pos4_from<0, NS>(lo, hi, f4, f1);
+}
+template <class F4, class F1> __device__ inline void for_pos4(int lo, int hi, F4 &&f4, F1 &&f1) { for_pos4_from<0, kSlots>(lo, hi, f4, f1); }
+// value at the (wave-uniform) position pos of a position-indexed vector
+template <int NS> __device__ inline double get_at(const double (&a)[NS], int pos) {
+    double r = rl(a[0], pos & 63);
+#pragma unroll
+    for (int s = 1; s < NS; ++s)
+        if ((pos >> 6) == s) r = rl(a[s], pos & 63);
+    return r;
+}
+template <int NS> __device__ inline int get_at_i(const int (&a)[NS], int pos) {
+    int r = __builtin_amdgcn_readlane(a[0], pos & 63);
+#pragma unroll
+    for (int s = 1; s < NS; ++s)
+        if ((pos >> 6) == s) r = __builtin_amdgcn_readlane(a[s], pos & 63);
+    return r;
 }
 // write v at (uniform) position pos.  Written as per-lane selects on purpose: the obvious "if ((pos >> 6) == s) a[s] = v"
 // chain is folded by the optimiser into ONE store with a run-time index, which demotes the whole array from registers
@@ -200,43 +211,43 @@ template <bool REV, int HB> __device__ __forceinline__ void band5(const double *
     o0 = a;
     o1 = b;
 }
-template <bool WANT_U, int HB, int NS>
+template <bool WANT_U, int HB, int NS, int KS>
 __device__ __forceinline__ void reg_terms_hb(double *xbuf, const double (&c)[5], int n, int p, int lane, const double (&x)[NS],
-                                    const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
-    // bin b lives at xbuf[2 + b]; two zero doubles in front of bin 0 and behind bin 255
+                                    const int (&pidx)[NS], double (&u)[KS], double *tt) {
+    // bin b lives at xbuf[2 + b]; two zero doubles in front of bin 0 and behind the last bin (64 KS - 1: 255 with four bins per lane)
     const double2 zero2 = {0.0, 0.0};
-    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
-    *reinterpret_cast<double2 *>(lo) = zero2;
-    *reinterpret_cast<double2 *>(hi) = zero2;
-    if (lane < 2) *reinterpret_cast<double2 *>(xbuf + 258 * lane) = zero2;
+    double *lo = xbuf + 2 + 2 * lane;  // pair h of this lane: lo + 128 h
+#pragma unroll
+    for (int h = 0; h < KS / 2; ++h) *reinterpret_cast<double2 *>(lo + 128 * h) = zero2;
+    if (lane < 2) *reinterpret_cast<double2 *>(xbuf + (kW * KS + 2) * lane) = zero2;
     lds_order();
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         if (lane + kW * s < p) xbuf[2 + pidx[s]] = x[s];
     lds_order();
-    double t[kSlots];
-    band5<false, HB>(lo, c, t[0], t[1]);
-    band5<false, HB>(hi, c, t[2], t[3]);
+    double t[KS];
+#pragma unroll
+    for (int h = 0; h < KS / 2; ++h) band5<false, HB>(lo + 128 * h, c, t[2 * h], t[2 * h + 1]);
     double acc = 0;
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < KS; ++s) {
         t[s] = (binof(lane, s) < n) ? t[s] : 0.0;  // rows >= n of R do not exist
         acc = fma(t[s], t[s], acc);
     }
     if (tt) *tt = acc;
     lds_order();
     if (!WANT_U) return;
-    *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
-    *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
+#pragma unroll
+    for (int h = 0; h < KS / 2; ++h) *reinterpret_cast<double2 *>(lo + 128 * h) = double2{t[2 * h], t[2 * h + 1]};
     lds_order();
-    band5<true, HB>(lo, c, u[0], u[1]);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
-    band5<true, HB>(hi, c, u[2], u[3]);
+#pragma unroll
+    for (int h = 0; h < KS / 2; ++h) band5<true, HB>(lo + 128 * h, c, u[2 * h], u[2 * h + 1]);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
     lds_order();
 }
 // hb (wave uniform): half bandwidth of the regulariser, 1 (orders 1 and 2 of the reference) or 2 (order 3)
-template <bool WANT_U, int NS>
+template <bool WANT_U, int NS, int KS>
 __device__ __forceinline__ void reg_terms(double *xbuf, const double (&c)[5], int hb, int n, int p, int lane, const double (&x)[NS],
-                                 const int (&pidx)[NS], double (&u)[kSlots], double *tt) {
+                                 const int (&pidx)[NS], double (&u)[KS], double *tt) {
     if (hb > 1)
         reg_terms_hb<WANT_U, 2>(xbuf, c, n, p, lane, x, pidx, u, tt);
     else

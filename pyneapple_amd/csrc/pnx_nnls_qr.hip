@@ -26,7 +26,6 @@ namespace pnx {
 
 namespace {
 constexpr int kW = 64;
-constexpr int kSlots = 4;
 constexpr int kNone = 1 << 30;
 
 struct QrArgs {
@@ -35,7 +34,7 @@ struct QrArgs {
     double *rnorm;
     int8_t *status;
     int32_t *iters;
-    const double *Bp;  // (n_meas, 256) zero padded rows
+    const double *Bp;  // (n_meas, 64 KB) zero padded rows
     long long n_vox;
     int n_meas, n_bins, max_iter;
 };
@@ -87,8 +86,11 @@ __device__ inline void givens(double f, double g, double &c, double &s, double &
     }
 }
 
-template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrArgs A) {
+// KB: bins per lane -- 4 up to 256 bins, 8 for the wide plans (257 .. 512 bins; the bins only appear in the dual, the arg-max,
+// the passive flags and the output)
+template <int MP, int KB> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrArgs A) {
     constexpr int ST = MP + 1;
+    constexpr int kBS = kW * KB;
     extern __shared__ double lds[];
     double *Qt = lds;             // [MP][ST]  Qt[i][m]: column i of Q
     double *Rc = Qt + MP * ST;    // [MP][ST]  Rc[k][i] = R[i][k]
@@ -106,7 +108,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
         double res = yv;                      // y - Q Q^T y, by measurement
         double xpos = 0, z = 0, qtb = 0, diag = 1;  // by position
         int pidx = 0;
-        bool inP[kSlots] = {false, false, false, false};
+        bool inP[KB] = {};
         int p = 0, iteration = 0, status = finite ? 1 : -2;
 
         int guard = 0;  // belt and braces: every pass of the loops below is counted; a voxel that exceeds any sane count stops
@@ -120,20 +122,22 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
             if (lane == 0 && guard < 40) printf("O vox=%lld p=%d it=%d guard=%d\n", vox, p, iteration, guard);
 #endif
             // ---- dual w = B^T res on the zero set
-            double w[kSlots] = {0, 0, 0, 0};
+            double w[KB] = {};
 #pragma unroll 4
             for (int k = 0; k < nm; ++k) {
                 const double rk = rl(res, k);
-                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
-                const double2 b0 = *reinterpret_cast<const double2 *>(br);
-                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
-                w[0] = fma(b0.x, rk, w[0]);
-                w[1] = fma(b0.y, rk, w[1]);
-                w[2] = fma(b1.x, rk, w[2]);
-                w[3] = fma(b1.y, rk, w[3]);
+                const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
+                double2 bh[KB / 2];
+#pragma unroll
+                for (int h = 0; h < KB / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+#pragma unroll
+                for (int h = 0; h < KB / 2; ++h) {
+                    w[2 * h] = fma(bh[h].x, rk, w[2 * h]);
+                    w[2 * h + 1] = fma(bh[h].y, rk, w[2 * h + 1]);
+                }
             }
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s)
+            for (int s = 0; s < KB; ++s)
                 if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
 
             bool accepted = false;
@@ -141,12 +145,14 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
             double lam = 0, qn = 0, l = 0, v = 0;
             for (;;) {
                 if (++guard > guard_max) break;
-                double best = fmax(fmax(w[0], w[1]), fmax(w[2], w[3]));
+                double best = w[0];
+#pragma unroll
+                for (int s = 1; s < KB; ++s) best = fmax(best, w[s]);
                 best = wave_max(best);
                 if (uni(!(best > 0))) break;  // KKT satisfied
                 int bj = kNone;
 #pragma unroll
-                for (int s = kSlots - 1; s >= 0; --s)
+                for (int s = KB - 1; s >= 0; --s)
                     if (w[s] == best) bj = binof(lane, s);
                 jmax = uni_i(wave_min_i(bj));
 #ifdef PNX_QR_TRACE
@@ -154,7 +160,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
 #endif
                 if (jmax >= n) break;  // cannot happen (some lane owns the maximum); never index B with it
                 // ---- candidate column a (by measurement), orthogonalised against Q twice
-                v = lane < nm ? A.Bp[(size_t)lane * kNnlsMaxBins + jmax] : 0.0;
+                v = lane < nm ? A.Bp[(size_t)lane * kBS + jmax] : 0.0;
                 l = 0;
                 for (int pass = 0; pass < 2; ++pass) {
                     lds_order();
@@ -188,7 +194,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
                     break;
                 }
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;  // reject: look for the next largest
             }
             if (!accepted) break;
@@ -210,7 +216,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
                     xpos = 0;
                 }
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == jmax) inP[s] = true;
                 p += 1;
             }
@@ -293,7 +299,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
                         }
                     }
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s)
+                    for (int s = 0; s < KB; ++s)
                         if (binof(lane, s) == bin_out) inP[s] = false;
                     p -= 1;
                     // round-off clean-up: any remaining x <= 0 leaves too (first position first)
@@ -308,13 +314,13 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
         if (lane == 0) printf("E vox=%lld status=%d it=%d p=%d guard=%d\n", vox, status, iteration, p, guard);
 #endif
         // ---- outputs
-        double xb[kSlots] = {0, 0, 0, 0};
+        double xb[KB] = {};
         if (status == 1) {
             for (int i = 0; i < p; ++i) {
                 const int b = __builtin_amdgcn_readlane(pidx, i);
                 const double xv = rl(xpos, i);
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == b) xb[s] = xv;
             }
         }
@@ -323,7 +329,7 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
 #endif
         double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < KB; ++s) {
             const int j = binof(lane, s);
             if (j < n) cv[j] = xb[s];
         }
@@ -354,9 +360,9 @@ template <int MP> __global__ void __launch_bounds__(kW) nnls_qr_kernel(const QrA
 
 template <int MP> size_t qr_lds_bytes() { return sizeof(double) * (2 * MP * (MP + 1) + 2 * kW); }
 
-template <int MP> int launch_qr(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
+template <int MP, int KB> int launch_qr(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
     static bool attr_done[64] = {false};
-    auto kern = nnls_qr_kernel<MP>;
+    auto kern = nnls_qr_kernel<MP, KB>;
     if (!attr_done[P->device & 63]) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qr_lds_bytes<MP>()) != hipSuccess)
             return set_error(PNX_ERR_HIP, "hipFuncSetAttribute(nnls_qr_kernel) failed");
@@ -396,7 +402,8 @@ struct QrBigArgs {
     double *slab;  // kQrSlab doubles per workgroup
 };
 
-__global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
+template <int KB> __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
+    constexpr int kBS = kW * KB;
     const QrArgs &A = BA.a;
     __shared__ double lbuf[kQM];  // (Q^T v) by position, read back with uniform addresses
     double *Qt = BA.slab + (size_t)blockIdx.x * kQrSlab;  // [kQM][kQST]  Qt[i][m]: column i of Q
@@ -423,7 +430,7 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
         }
         const bool finite = __all(fin ? 1 : 0) != 0;
         const double yn2 = wave_sum(y2);
-        bool inP[kSlots] = {false, false, false, false};
+        bool inP[KB] = {};
         int p = 0, iteration = 0, status = finite ? 1 : -2;
         int guard = 0;
         const int guard_max = 8 * A.max_iter + 4 * n + 64;
@@ -433,20 +440,22 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
                 break;
             }
             // ---- dual w = B^T res on the zero set
-            double w[kSlots] = {0, 0, 0, 0};
+            double w[KB] = {};
 #pragma unroll 4
             for (int k = 0; k < nm; ++k) {
                 const double rk = rlk(res, k);
-                const double *br = A.Bp + (size_t)k * kNnlsMaxBins + 2 * lane;
-                const double2 b0 = *reinterpret_cast<const double2 *>(br);
-                const double2 b1 = *reinterpret_cast<const double2 *>(br + 128);
-                w[0] = fma(b0.x, rk, w[0]);
-                w[1] = fma(b0.y, rk, w[1]);
-                w[2] = fma(b1.x, rk, w[2]);
-                w[3] = fma(b1.y, rk, w[3]);
+                const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
+                double2 bh[KB / 2];
+#pragma unroll
+                for (int h = 0; h < KB / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+#pragma unroll
+                for (int h = 0; h < KB / 2; ++h) {
+                    w[2 * h] = fma(bh[h].x, rk, w[2 * h]);
+                    w[2 * h + 1] = fma(bh[h].y, rk, w[2 * h + 1]);
+                }
             }
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s)
+            for (int s = 0; s < KB; ++s)
                 if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
 
             bool accepted = false;
@@ -455,12 +464,14 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
             double l[kQS] = {0, 0}, v[kQS] = {0, 0};
             for (;;) {
                 if (++guard > guard_max) break;
-                double best = fmax(fmax(w[0], w[1]), fmax(w[2], w[3]));
+                double best = w[0];
+#pragma unroll
+                for (int s = 1; s < KB; ++s) best = fmax(best, w[s]);
                 best = wave_max(best);
                 if (uni(!(best > 0))) break;  // KKT satisfied
                 int bj = kNone;
 #pragma unroll
-                for (int s = kSlots - 1; s >= 0; --s)
+                for (int s = KB - 1; s >= 0; --s)
                     if (w[s] == best) bj = binof(lane, s);
                 jmax = uni_i(wave_min_i(bj));
                 if (jmax >= n) break;
@@ -468,7 +479,7 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
 #pragma unroll
                 for (int s = 0; s < kQS; ++s) {
                     const int m = lane + kW * s;
-                    v[s] = m < nm ? A.Bp[(size_t)m * kNnlsMaxBins + jmax] : 0.0;
+                    v[s] = m < nm ? A.Bp[(size_t)m * kBS + jmax] : 0.0;
                     l[s] = 0;
                 }
                 for (int pass = 0; pass < 2; ++pass) {
@@ -514,7 +525,7 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
                     break;
                 }
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;  // reject: look for the next largest
             }
             if (!accepted) break;
@@ -538,7 +549,7 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
                 }
                 sync();
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == jmax) inP[s] = true;
                 p += 1;
             }
@@ -671,7 +682,7 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
                         }
                     }
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s)
+                    for (int s = 0; s < KB; ++s)
                         if (binof(lane, s) == bin_out) inP[s] = false;
                     p -= 1;
                     // round-off clean-up: any remaining x <= 0 leaves too (first position first)
@@ -686,19 +697,19 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
             }
         }
         // ---- outputs
-        double xb[kSlots] = {0, 0, 0, 0};
+        double xb[KB] = {};
         if (status == 1) {
             for (int i = 0; i < p; ++i) {
                 const int b = rlk_i(pidx, i);
                 const double xv = rlk(xpos, i);
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == b) xb[s] = xv;
             }
         }
         double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) {
+        for (int s = 0; s < KB; ++s) {
             const int j = binof(lane, s);
             if (j < n) cv[j] = xb[s];
         }
@@ -716,9 +727,9 @@ __global__ void __launch_bounds__(kW) nnls_qr_big_kernel(const QrBigArgs BA) {
     }
 }
 
-int launch_qr_big(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
+template <int KB> int launch_qr_big(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_qr_big_kernel, kW, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_qr_big_kernel<KB>, kW, 0) != hipSuccess || occ < 1)
         return set_error(PNX_ERR_HIP, "nnls_qr_big_kernel does not fit on a CU");
     if (occ > 8) occ = 8;  // 264 KB of Q / R per wave: 8 waves per CU are 540 MB of slab, of which a fit touches the rows of its passive set
     long long grid = (long long)occ * P->cus;
@@ -735,7 +746,7 @@ int launch_qr_big(NnlsPlanData *P, const QrArgs &a, hipStream_t stream) {
     QrBigArgs ba;
     ba.a = a;
     ba.slab = P->qr_slab;
-    hipLaunchKernelGGL(nnls_qr_big_kernel, dim3((unsigned)grid), dim3(kW), 0, stream, ba);
+    hipLaunchKernelGGL(nnls_qr_big_kernel<KB>, dim3((unsigned)grid), dim3(kW), 0, stream, ba);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "nnls_qr_big launch: %s", hipGetErrorString(e));
     return PNX_OK;
@@ -761,9 +772,11 @@ int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int 
         // per CU is the faster one there too: 4.16 against 2.82 M voxels/s at 33 b-values, 2.85 against 1.72 M at 64
         // (profiles/nnls_cliff_probe.py); PNX_NNLS_QR_SLAB_FROM=65 brings the LDS kernel back for comparison
         static const int slab_from = getenv("PNX_NNLS_QR_SLAB_FROM") ? atoi(getenv("PNX_NNLS_QR_SLAB_FROM")) : 33;
-        if (P->n_meas >= slab_from || P->n_meas > 64) return launch_qr_big(P, a, stream);
+        const bool wide = P->bstride == kNnlsWideBins;
+        if (P->n_meas >= slab_from || P->n_meas > 64) return wide ? launch_qr_big<8>(P, a, stream) : launch_qr_big<4>(P, a, stream);
+        if (wide) return P->n_meas <= 32 ? launch_qr<32, 8>(P, a, stream) : launch_qr<64, 8>(P, a, stream);
     }
-    return P->n_meas <= 32 ? launch_qr<32>(P, a, stream) : launch_qr<64>(P, a, stream);
+    return P->n_meas <= 32 ? launch_qr<32, 4>(P, a, stream) : launch_qr<64, 4>(P, a, stream);
 }
 
 }  // namespace pnx

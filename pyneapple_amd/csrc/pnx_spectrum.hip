@@ -28,7 +28,8 @@
 namespace pnx {
 namespace {
 constexpr int kW = 64;
-constexpr int kMaxBins = 256;
+constexpr int kNarrowBins = 256;  // four bins per lane, the bin centres travel in the kernel arguments
+constexpr int kMaxBins = 512;     // eight bins per lane (the wide NNLS plans), the bin centres in a device buffer
 constexpr int kMaxPeaks = 64;  // per voxel: peak k of the list lives in lane k of the wave that owns the spectrum
 constexpr int kSeqPeaks = 16;  // the one-lane path of flat-topped spectra keeps its list in registers: 16 (NaN rows beyond)
 constexpr int kMaxCut = 8;
@@ -38,7 +39,9 @@ struct PeakArgs {
     long long n_vox;
     int n_bins, max_peaks, n_cut, regularized;
     double height, rel_height;
-    double bins[kMaxBins];  // by value: no device allocation, nothing to wait for in device mode
+    double bins[kNarrowBins];  // by value: no device allocation, nothing to wait for in device mode
+    const double *bins_wide;   // more than 256 bins (a kernel's arguments end at 4 KB): device copy, stream ordered
+    __device__ double bin(int j) const { return bins_wide ? bins_wide[j] : bins[j]; }
     int32_t *n_peaks;    // (n_vox)
     double *d_values;    // (n_vox, max_peaks) NaN padded, may be null
     double *f_values;    // (n_vox, max_peaks)
@@ -134,7 +137,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
                 f = xp * fwhm / (2.0 * sqrt(2.0 * log(2.0))) * sqrt(2.0 * 3.141592653589793);
             }
             fv[k] = f;
-            dv[k] = A.bins[peak];
+            dv[k] = A.bin(peak);
             fsum += f;
         }
     }
@@ -211,7 +214,7 @@ __device__ void peaks_sequential(const PeakArgs &A, const double *x, long long v
     }
 }
 
-// ---- wave-parallel version: one wavefront owns one spectrum, four bins per lane (bin = 64 s + lane) ---------------
+// ---- wave-parallel version: one wavefront owns one spectrum, four (eight) bins per lane (bin = 64 s + lane) ---------------
 __device__ inline double wmin(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
@@ -222,68 +225,74 @@ __device__ inline double wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-struct Mask4 {  // one bit per bin
-    unsigned long long m[4];
+template <int NS> struct MaskN {  // one bit per bin
+    unsigned long long m[NS];
 };
-__device__ inline Mask4 ballot4(const bool (&c)[4]) {
-    Mask4 r;
+template <int NS> __device__ inline MaskN<NS> ballot4(const bool (&c)[NS]) {
+    MaskN<NS> r;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) r.m[s] = __ballot(c[s] ? 1 : 0);
+    for (int s = 0; s < NS; ++s) r.m[s] = __ballot(c[s] ? 1 : 0);
     return r;
 }
-__device__ inline int highest(const Mask4 &k) {  // index of the highest set bit, -1 if none
+template <int NS> __device__ inline int highest(const MaskN<NS> &k) {  // index of the highest set bit, -1 if none
 #pragma unroll
-    for (int s = 3; s >= 0; --s)
+    for (int s = NS - 1; s >= 0; --s)
         if (k.m[s]) return 64 * s + 63 - __builtin_clzll(k.m[s]);
     return -1;
 }
-__device__ inline int lowest(const Mask4 &k, int none) {
+template <int NS> __device__ inline int lowest(const MaskN<NS> &k, int none) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NS; ++s)
         if (k.m[s]) return 64 * s + __builtin_ctzll(k.m[s]);
     return none;
 }
 
-__global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
-    __shared__ double rows[4][kMaxBins + 8];  // per wave: the spectrum, one pad sample on either side
+// NS: bins per lane (4 up to 256 bins, 8 up to 512)
+template <int NS> __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
+    __shared__ double rows[4][64 * NS + 8];  // per wave: the spectrum, one pad sample on either side
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = A.n_bins;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     double *xr = rows[wave] + 1;  // xr[-1] and xr[n] exist
     for (long long vox = (long long)blockIdx.x * 4 + wave; vox < A.n_vox; vox += (long long)gridDim.x * 4) {
         const double *src = A.spec + (size_t)vox * n;
-        double v[4];
-        int j[4];
+        double v[NS];
+        int j[NS];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             j[s] = 64 * s + lane;
             v[s] = j[s] < n ? src[j[s]] : 0.0;  // coalesced: 512 bytes per instruction
         }
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xr[j[s]] = v[s];
+        for (int s = 0; s < NS; ++s) xr[j[s]] = v[s];
         if (lane == 0) {
             xr[-1] = 0.0;
             xr[n] = 0.0;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its LDS instructions execute in order
         // ---- _local_maxima_1d without plateaus + the height condition
-        bool pk[4], flat[4];
+        bool pk[NS], flat[NS];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const bool in = j[s] >= 1 && j[s] <= n - 2;
             const double xm = xr[j[s] - 1], xp = in ? xr[j[s] + 1] : 0.0;
             const bool rise = in && xm < v[s];
             pk[s] = rise && v[s] > xp && A.height <= v[s];
             flat[s] = rise && v[s] == xp;
         }
-        if (__any((flat[0] || flat[1] || flat[2] || flat[3]) ? 1 : 0)) {
+        bool anyflat = false;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) anyflat = anyflat || flat[s];
+        if (__any(anyflat ? 1 : 0)) {
             if (lane == 0) peaks_sequential(A, xr, vox);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             continue;
         }
-        Mask4 peaks = ballot4(pk);
-        const int total = __popcll(peaks.m[0]) + __popcll(peaks.m[1]) + __popcll(peaks.m[2]) + __popcll(peaks.m[3]);
+        MaskN<NS> peaks = ballot4(pk);
+        int total = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) total += __popcll(peaks.m[s]);
         if (total > kMaxPeaks) {  // more peaks than the table (one per lane) holds: NaN, never a partial normalisation
             if (A.n_peaks && lane == 0) A.n_peaks[vox] = total;
             if (A.d_values && lane < A.max_peaks) A.d_values[(size_t)vox * A.max_peaks + lane] = A.f_values[(size_t)vox * A.max_peaks + lane] = nan;
@@ -294,7 +303,7 @@ __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
         // peak k of the list lives in lane k
         double dval = nan, fval = nan;
         int m = 0;
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             unsigned long long bits = peaks.m[s];
             while (bits && m < kMaxPeaks) {
                 const int p = 64 * s + __builtin_ctzll(bits);
@@ -304,35 +313,35 @@ __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
                 if (A.regularized) {
                     // _peak_prominences (wlen = None): nearest higher sample on either side bounds the scan; the base is the
                     // lowest sample in between, the one closest to the peak among equals
-                    bool c[4];
+                    bool c[NS];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] < p && v[t] > xp;
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] < p && v[t] > xp;
                     const int L = highest(ballot4(c));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] > p && j[t] < n && v[t] > xp;
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] > p && j[t] < n && v[t] > xp;
                     const int R = lowest(ballot4(c), n);
                     double a = INFINITY, b = INFINITY;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < NS; ++t) {
                         if (j[t] > L && j[t] <= p) a = fmin(a, v[t]);
                         if (j[t] >= p && j[t] < R) b = fmin(b, v[t]);
                     }
                     const double lmin = wmin(a), rmin = wmin(b);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] > L && j[t] <= p && v[t] == lmin;
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] > L && j[t] <= p && v[t] == lmin;
                     const int lb = highest(ballot4(c));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] >= p && j[t] < R && v[t] == rmin;
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] >= p && j[t] < R && v[t] == rmin;
                     const int rb = lowest(ballot4(c), p);
                     const double prom = xp - fmax(lmin, rmin);
                     // _peak_widths: first sample at or below the evaluation height on either side, not beyond the bases
                     const double h = xp - prom * A.rel_height;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] > lb && j[t] <= p && !(h < v[t]);
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] > lb && j[t] <= p && !(h < v[t]);
                     int li = highest(ballot4(c));
                     if (li < 0) li = lb;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) c[t] = j[t] >= p && j[t] < rb && !(h < v[t]);
+                    for (int t = 0; t < NS; ++t) c[t] = j[t] >= p && j[t] < rb && !(h < v[t]);
                     const int ri = lowest(ballot4(c), rb);
                     double lip = (double)li, rip = (double)ri;
                     const double xl = xr[li], xrr = xr[ri];
@@ -342,7 +351,7 @@ __global__ void __launch_bounds__(256) spectrum_peaks_kernel(const PeakArgs A) {
                     f = xp * fwhm / (2.0 * sqrt(2.0 * log(2.0))) * sqrt(2.0 * 3.141592653589793);  // spectrum.py:44-47
                 }
                 if (lane == m) {
-                    dval = A.bins[p];
+                    dval = A.bin(p);
                     fval = f;
                 }
                 ++m;
@@ -461,7 +470,9 @@ int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectru
     a.regularized = regularized;
     a.height = height;
     a.rel_height = rel_height;
-    for (int j = 0; j < kMaxBins; ++j) a.bins[j] = j < n_bins ? bins_host[j] : 0.0;
+    const bool wide = n_bins > kNarrowBins;
+    for (int j = 0; j < kNarrowBins; ++j) a.bins[j] = (!wide && j < n_bins) ? bins_host[j] : 0.0;
+    a.bins_wide = nullptr;
     for (int c = 0; c < 2 * n_cut; ++c) a.cut[c] = cutoffs_host[c];
     const size_t nv = (size_t)n_vox;
     if (mem == PNX_MEM_DEVICE) {
@@ -497,8 +508,22 @@ int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectru
     long long grid = (n_vox + 3) / 4;
     const long long cap = (long long)prop.multiProcessorCount * 8;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(spectrum_peaks_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-    PNX_HIPS(hipGetLastError());
+    if (wide) {  // stream ordered: allocated, filled (the copy from pageable memory is staged before the call returns), used, freed
+        double *dbins = nullptr;
+        PNX_HIPS(hipMallocAsync((void **)&dbins, (size_t)n_bins * sizeof(double), st));
+        hipError_t e = hipMemcpyAsync(dbins, bins_host, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, st);
+        a.bins_wide = dbins;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(spectrum_peaks_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, a);
+            e = hipGetLastError();
+        }
+        const hipError_t e2 = hipFreeAsync(dbins, st);
+        if (e != hipSuccess || e2 != hipSuccess)
+            return pnx::set_error(PNX_ERR_HIP, "wide spectrum launch: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    } else {
+        hipLaunchKernelGGL(spectrum_peaks_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, a);
+        PNX_HIPS(hipGetLastError());
+    }
     if (mem == PNX_MEM_HOST) {
         if (n_peaks) PNX_HIPS(hipMemcpyAsync(n_peaks, a.n_peaks, nv * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (max_peaks) {

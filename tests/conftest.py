@@ -78,7 +78,10 @@ def check_g7(r, d, kw, amp):
 
 
 NNLS_FIXTURES = ["g4_nnls_250_r2", "g4_nnls_250_r1", "g4_nnls_250_r3", "g4_nnls_50_r2", "g4_nnls_50_r0",
-                 "g4_nnls_250_r2_maxiter20", "g9_nnls_250_r0"]  # g9_nnls_250_r0: the reference's default reg_order=0
+                 "g4_nnls_250_r2_maxiter20", "g9_nnls_250_r0",  # g9_nnls_250_r0: the reference's default reg_order=0
+                 # round 4: more than 256 bins (the wide instantiations; 512 bins: two voxels run into max_iter = 250)
+                 "g11_nnls_300_r2", "g11_nnls_512_r2", "g11_nnls_350_r1", "g11_nnls_300_r3", "g11_nnls_400_r0",
+                 "g11_nnls_300_r2_maxiter20"]
 
 
 def many_fixed_cases():

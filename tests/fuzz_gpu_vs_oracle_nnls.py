@@ -4,7 +4,7 @@ on a GPU box; tests/test_gpu_parity_large.py runs 100 fixed-seed cases of it in 
 D range, regulariser (none, orders 0-3, a dense random matrix), mu, signal scale 1e-6..1e6, noise, number of
 compartments, iteration limit (tiny, default, 0 = SciPy's 3 n).  With a regulariser of full column rank the minimiser
 is unique: coefficients are compared (1e-6 of the spectrum peak), as are status, rnorm and the iteration counts.
-Without one (or order 0) only status, rnorm and non-negativity are compared."""
+Without one (or order 0) only status, rnorm and non-negativity are compared.  `--wide`: the same cases with 257..512 bins."""
 from __future__ import annotations
 
 import os
@@ -17,7 +17,7 @@ from oracle import pnx_oracle as oracle  # noqa: E402
 from pyneapple_amd import api  # noqa: E402
 
 
-def run(n_cases=200, seed=0, verbose=True, n_threads=8):
+def run(n_cases=200, seed=0, verbose=True, n_threads=8, wide=False):
     """n_cases random cases from `seed`; returns the summary dict that `--json` writes and the GPU suite asserts on."""
     print_ = print if verbose else (lambda *a, **k: None)
     rng = np.random.default_rng(seed)
@@ -26,6 +26,8 @@ def run(n_cases=200, seed=0, verbose=True, n_threads=8):
     for c in range(n_cases):
         n_meas = int(rng.integers(3, 65))
         n_bins = int(rng.choice([4, 7, 16, 50, 63, 64, 65, 128, 250, 256]))
+        if wide:  # the eight-bins-per-lane instantiations (same draws otherwise: the narrow cases of a seed stay what they were)
+            n_bins = [257, 300, 320, 384, 400, 450, 500, 511, 512, 300][c % 10]
         n_vox = int(rng.choice([1, 5, 64, 200]))
         b = np.sort(rng.uniform(0, float(rng.choice([800, 1500])), n_meas))
         b[0] = 0.0
@@ -84,7 +86,7 @@ def run(n_cases=200, seed=0, verbose=True, n_threads=8):
     print_(f"{n_cases} cases, {tot} voxels: status {stat_bad}, coefficients {coef_bad}, rnorm {rn_bad}, iteration-count {iter_bad} disagreements; failing cases {bad}")
     from pyneapple_amd import _build
 
-    return {"fuzzer": "nnls", "n_cases": n_cases, "seed": seed, "voxels": tot, "status_disagreements": stat_bad,
+    return {"fuzzer": "nnls" + (" (257..512 bins)" if wide else ""), "n_cases": n_cases, "seed": seed, "voxels": tot, "status_disagreements": stat_bad,
             "coefficient_disagreements": coef_bad, "rnorm_disagreements": rn_bad, "iteration_count_disagreements": iter_bad,
             "failing_cases": bad,
             "thresholds": {"coefficients": "1e-6 of the spectrum peak (regularisers of full column rank)",
@@ -101,9 +103,12 @@ def main():
         i = sys.argv.index("--json")
         out = sys.argv[i + 1]
         del sys.argv[i:i + 2]
+    wide = "--wide" in sys.argv
+    if wide:
+        sys.argv.remove("--wide")
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    res = run(n_cases, seed)
+    res = run(n_cases, seed, wide=wide)
     if out:
         with open(out, "w") as fh:
             json.dump(res, fh, indent=1)

@@ -87,7 +87,78 @@ def test_edge_shapes_and_failures(gpu, oracle):
     assert r["status"][0] == 0 and r["status"][1] == -2 and (r["coefficients"][:2] == 0).all()
     assert r["residual"][0] == pytest.approx(np.linalg.norm(y[0])) and np.isnan(r["residual"][1])
     with pytest.raises(Exception):
-        gpu.nnls(np.ones((4, 300)), None, np.ones((1, 4)))  # > 256 bins: refused, not silently wrong
+        gpu.nnls(np.ones((4, 600)), None, np.ones((1, 4)))  # > 512 bins: refused, not silently wrong
+
+
+@pytest.mark.parametrize("n_bins,order,n_b", [(300, 2, 32), (512, 2, 32), (257, 1, 16), (384, 3, 48), (300, 2, 96)])
+def test_wide_regularised_plans_match_oracle(gpu, oracle, n_bins, order, n_b):
+    """More than 256 bins (the reference takes any n_bins, models/nnls.py:37-77; refused up to round 3): the Gram-form kernel
+    with eight bins per lane must walk the oracle's active-set path -- status (512 bins run into max_iter = 250 on some
+    voxels), iteration counts, supports."""
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, reg_order=order, n_bins=n_bins)
+    _, basis, reg = synth.nnls_matrices(n_b, cfg)
+    assert basis.shape == (n_b, n_bins)
+    _, y, _ = synth.make_numpy("tri_reduced", 384, n_b, sigma=0.01, seed=123, scale=1000.0)
+    r = gpu.nnls(basis, reg, y, 250)
+    o = oracle.nnls(basis, reg, y, 250, n_threads=8)
+    np.testing.assert_array_equal(r["status"], o["status"])
+    ok = o["status"] == 1
+    assert ok.mean() > 0.5
+    assert _scaled_err(r["coefficients"][ok], o["coefficients"][ok]).max() < 1e-6
+    np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9)
+    np.testing.assert_allclose(r["residual"][~ok], np.linalg.norm(y[~ok], axis=1), rtol=1e-14)
+    assert (r["coefficients"][~ok] == 0).all()
+    assert (r["iters"] == o["iters"]).mean() > 0.99
+    assert (((r["coefficients"] > 0) != (o["coefficients"] > 0)).sum(axis=1) == 0).mean() > 0.99
+
+
+@pytest.mark.parametrize("n_b,n_bins", [(32, 300), (24, 512), (64, 400), (96, 300), (128, 512)])
+def test_wide_unregularised_plans_match_oracle(gpu, oracle, n_b, n_bins):
+    """reg_order = 0 with more than 256 bins: the QR-form kernels with eight bins per lane (Q / R in LDS up to 32 measurements, in
+    the per-wave slab beyond)."""
+    from pyneapple_amd import synth
+
+    bins = np.logspace(np.log10(0.0008), np.log10(0.5), n_bins)
+    b = np.linspace(0.0, 1200.0, n_b)
+    basis = np.exp(-b[:, None] * bins[None, :])
+    _, y, _ = synth.make_numpy("tri_reduced", 1000, n_b, sigma=0.01, seed=7, scale=1000.0)
+    for reg in (None, np.zeros((n_bins, n_bins))):
+        r = gpu.nnls(basis, reg, y, 400)
+        o = oracle.nnls(basis, reg, y, 400, n_threads=8)
+        np.testing.assert_array_equal(r["status"], o["status"])
+        ok = o["status"] == 1
+        assert ok.mean() > 0.9
+        same = ((r["coefficients"] > 0) == (o["coefficients"] > 0)).all(axis=1)
+        assert same[ok].mean() > 0.99, f"supports differ on {(~same[ok]).sum()} voxels"
+        assert (r["iters"] == o["iters"])[ok].mean() > 0.99
+        assert _scaled_err(r["coefficients"][ok & same], o["coefficients"][ok & same]).max() < 1e-6
+        np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9)
+        assert (r["coefficients"] >= 0).all()
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_wide_passive_set_beyond_256_positions(gpu, oracle, dense):
+    """A strongly damped fit of a positive combination of ALL 300 columns: every bin enters, the passive set grows through the
+    fifth register slot of the position-indexed vectors of the eight-slot kernel, the overflow rows of the inverse factor reach
+    row 299 of its slab; with a dense (non-Toeplitz) regulariser the generic rows-of-reg epilogue runs too."""
+    rng = np.random.default_rng(5)
+    n_b, n_bins = 128, 300
+    basis = np.abs(rng.standard_normal((n_b, n_bins)))
+    reg = 3.0 * np.eye(n_bins)
+    if dense:
+        reg = reg + 0.05 * rng.standard_normal((n_bins, n_bins))
+    x_true = rng.uniform(0.5, 2.0, (24, n_bins))
+    x_true[:, ::11] = 0.0
+    y = x_true @ basis.T + 1e-3 * rng.standard_normal((24, n_b))
+    r = gpu.nnls(basis, reg, y, 2000)
+    o = oracle.nnls(basis, reg, y, 2000, n_threads=8)
+    np.testing.assert_array_equal(r["status"], o["status"])
+    assert (o["status"] == 1).all() and ((o["coefficients"] > 0).sum(axis=1) > 256).any()
+    assert (r["iters"] == o["iters"]).mean() > 0.9
+    assert _scaled_err(r["coefficients"], o["coefficients"]).max() < 1e-8
+    np.testing.assert_allclose(r["residual"], o["residual"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("n_b,n_bins", [(96, 250), (65, 250), (128, 256), (100, 60), (48, 250), (33, 120), (64, 250)])
@@ -317,3 +388,58 @@ def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
     for k in ("coefficients", "residual", "status", "iters"):
         np.testing.assert_array_equal(many[k], one[k], err_msg=k)
     assert (one["status"] == 1).all()
+
+
+def test_wide_plan_through_every_host_path(gpu, oracle, monkeypatch):
+    """A 300-bin spectrum (refused up to round 3) through the paths a Pyneapple user reaches: host arrays in chunks, float32
+    storage, the fused solve + peak tables, device-resident tensors -- all equal to one another, and the plain call to the oracle."""
+    import torch
+
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, n_bins=300)
+    bins, basis, reg = synth.nnls_matrices(32, cfg)
+    _, y, _ = synth.make_numpy("tri_reduced", 5000 + 13, 32, sigma=0.01, seed=31, scale=1000.0)
+    o = oracle.nnls(basis, reg, y[:512], 250, n_threads=8)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    one = plan.solve(y, 250)
+    np.testing.assert_array_equal(one["status"][:512], o["status"])
+    assert _scaled_err(one["coefficients"][:512], o["coefficients"]).max() < 1e-6
+    assert (one["iters"][:512] == o["iters"]).mean() > 0.99
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "1024")
+    many = plan.solve(y, 250)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many[k], one[k], err_msg=k)
+    y32 = y.astype(np.float32)
+    f32 = plan.solve(y32, 250)
+    assert f32["coefficients"].dtype == np.float32
+    ref32 = plan.solve(y32.astype(np.float64), 250)
+    np.testing.assert_array_equal(f32["coefficients"], ref32["coefficients"].astype(np.float32))
+    np.testing.assert_array_equal(f32["iters"], ref32["iters"])
+    # device-resident
+    dev = torch.device("cuda", 0)
+    yd = torch.from_numpy(y).to(dev)
+    n = y.shape[0]
+    coeff = torch.empty((n, 300), dtype=torch.float64, device=dev)
+    rn = torch.empty(n, dtype=torch.float64, device=dev)
+    st = torch.empty(n, dtype=torch.int8, device=dev)
+    it = torch.empty(n, dtype=torch.int32, device=dev)
+    plan.solve_device(n, yd, 250, coeff, rn, st, it, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(coeff.cpu().numpy(), one["coefficients"])
+    np.testing.assert_array_equal(it.cpu().numpy(), one["iters"])
+    # fused solve + peak tables
+    cuts = [(0.0008, 0.003), (0.003, 0.02), (0.02, 0.5)]
+    ref = gpu.spectrum_peaks(one["coefficients"], bins, height=0.1, regularized=True, max_peaks=8, cutoffs=cuts)
+    monkeypatch.setenv("PNX_NNLS_PEAKS_CHUNK", "2000")
+    pk = plan.solve_peaks(y, bins, max_iter=250, height=0.1, regularized=True, max_peaks=8, cutoffs=cuts)
+    for k in ("n_peaks", "d_values", "f_values", "d_cut", "f_cut"):
+        np.testing.assert_array_equal(pk[k], ref[k], err_msg=k)
+    np.testing.assert_array_equal(pk["residual"], one["residual"])
+    plan.close()
+    with pytest.raises(Exception):  # the MFMA Gram step on its own is a 256-column layout: refused for a wide plan, loudly
+        p2 = gpu.NnlsPlan(basis, reg, 0)
+        try:
+            p2.aty_device(16, yd[:16], None, torch.cuda.current_stream().cuda_stream)
+        finally:
+            p2.close()

@@ -61,6 +61,20 @@ def test_nnls_fuzz_100_cases(gpu, oracle):
     assert r["rnorm_disagreements"] <= 2, r
 
 
+def test_nnls_fuzz_wide_40_cases(gpu, oracle):
+    """The same fuzzer on the eight-bins-per-lane instantiations (257..512 bins): Gram form with the reference's and with dense
+    regularisers, QR form without one."""
+    r = _load("tests/fuzz_gpu_vs_oracle_nnls.py", "fuzz_nnls").run(40, seed=20261005, verbose=True, wide=True)
+    # 200-case run (profiles/r04_fuzz_nnls_wide.json): status 12 (8 of them in one unregularised max_iter = 20 case, the others
+    # single voxels where one side cycles into max_iter = 250 and the other converges -- the iteration counts of 300-512 bin fits
+    # sit much closer to the limit than those of 250-bin fits), coefficients 10 (1.6e-6 .. 2.7e-6 of the peak at mu <= 0.02),
+    # rnorm 0 in 12 643 voxels
+    assert r["voxels"] > 1000
+    assert r["status_disagreements"] <= 0.004 * r["voxels"] + 8, r
+    assert r["coefficient_disagreements"] <= 0.002 * r["voxels"] + 4, r
+    assert r["rnorm_disagreements"] <= 2, r
+
+
 def test_streamed_host_path_fuzz_40_cases(gpu):
     """Random configurations of the streamed host path against the chunk ring (tests/fuzz_stream_vs_ring.py): bit-identical
     outputs, no watermark time-out, streamed exactly when the batch has two or more granules."""

@@ -219,6 +219,31 @@ class TestReferenceContractOddsAndEnds:
         c = s.params_["coefficients"]
         assert c.shape == (1, 50) and (c >= 0).all() and s.diagnostics_["residual"].shape == (1,)
 
+    @pytest.mark.parametrize("reg_order,n_bins", [(0, 300), (2, 300), (2, 512), (1, 400)])
+    def test_nnls_plugin_with_more_than_256_bins_matches_the_golden_reference(self, gpu, reg_order, n_bins):
+        """The reference accepts any n_bins (models/nnls.py:37-77).  Through the plugin class, against fixtures the reference
+        itself produced (oracle/gen_golden.py g11) where one exists for the shape, else shapes / KKT only."""
+        from conftest import GOLDEN, load_golden
+        import os
+
+        name = {(2, 300): "g11_nnls_300_r2", (2, 512): "g11_nnls_512_r2", (0, 400): "g11_nnls_400_r0"}.get((reg_order, n_bins))
+        if name and os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+            d = load_golden(name)
+            s = HipNNLSSolver(model=NNLSModel(d_range=tuple(d["d_range"]), n_bins=n_bins), reg_order=reg_order, mu=float(d["mu"]),
+                              max_iter=int(d["max_iter"])).fit(d["bvalues"], d["y"])
+            c = s.params_["coefficients"]
+            ok = d["success"]
+            scale = np.abs(d["coefficients"]).max(axis=1, keepdims=True) + 1e-300
+            assert (np.abs(c - d["coefficients"]) / scale).max() < 1e-6
+            np.testing.assert_allclose(s.diagnostics_["residual"], d["residual"], rtol=1e-10)
+            assert [r.success for r in s.pixel_results_] == list(ok)
+        else:
+            b = np.linspace(0, 1200, 32)
+            y = np.tile(300 * np.exp(-b * 0.05) + 700 * np.exp(-b * 0.001), (5, 1))
+            s = HipNNLSSolver(model=NNLSModel(d_range=(0.0008, 0.5), n_bins=n_bins), reg_order=reg_order, mu=0.02).fit(b, y)
+            c = s.params_["coefficients"]
+            assert c.shape == (5, n_bins) and (c >= 0).all() and (c[0] == c[4]).all() and c.sum() > 0
+
     def test_nnls_results_are_copies_and_refit_resets(self, gpu):
         b = np.linspace(0, 1000, 16)
         y = np.tile(np.exp(-b * 2e-3), (3, 1))

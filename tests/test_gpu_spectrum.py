@@ -1,4 +1,5 @@
-"""NNLS spectrum post-processing on the device against the reference's own utility/spectrum.py (fixtures g9_spectrum_*:
+"""NNLS spectrum post-processing on the device against the reference's own utility/spectrum.py (fixtures g9_spectrum_*, and
+g11_spectrum_* with 300 / 400 / 512 bins:
 find_spectrum_peaks + apply_cutoffs run on reference NNLS spectra by oracle/gen_golden.py), plus scipy.signal directly on
 adversarial rows (plateaus, peaks at the border, ties)."""
 from __future__ import annotations
@@ -11,7 +12,7 @@ import pytest
 from conftest import GOLDEN, load_golden
 
 pytestmark = pytest.mark.gpu
-FIXTURES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "g9_spectrum_*.npz")))
+FIXTURES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "g*_spectrum_*.npz")))
 
 
 @pytest.mark.parametrize("name", FIXTURES)
