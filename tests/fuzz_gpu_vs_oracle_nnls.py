@@ -23,6 +23,7 @@ def run(n_cases=200, seed=0, verbose=True, n_threads=8, wide=False):
     rng = np.random.default_rng(seed)
     bad = 0
     tot = coef_bad = stat_bad = iter_bad = rn_bad = 0
+    ce_max = 0.0
     for c in range(n_cases):
         n_meas = int(rng.integers(3, 65))
         n_bins = int(rng.choice([4, 7, 16, 50, 63, 64, 65, 128, 250, 256]))
@@ -65,6 +66,8 @@ def run(n_cases=200, seed=0, verbose=True, n_threads=8, wide=False):
         peak = np.abs(o["coefficients"]).max(axis=1) + 1e-300
         ce = np.abs(r["coefficients"] - o["coefficients"]).max(axis=1) / peak
         cb = ok & (ce > 1e-6) if unique else np.zeros(n_vox, bool)
+        if unique and ok.any():
+            ce_max = max(ce_max, float(ce[ok].max()))
         # without a regulariser the system is rank deficient and often exactly solvable: rnorm is then rounding noise
         # times the condition number -- compare it against the signal norm there
         ynorm = np.linalg.norm(np.nan_to_num(y), axis=1)
@@ -88,7 +91,7 @@ def run(n_cases=200, seed=0, verbose=True, n_threads=8, wide=False):
 
     return {"fuzzer": "nnls" + (" (257..512 bins)" if wide else ""), "n_cases": n_cases, "seed": seed, "voxels": tot, "status_disagreements": stat_bad,
             "coefficient_disagreements": coef_bad, "rnorm_disagreements": rn_bad, "iteration_count_disagreements": iter_bad,
-            "failing_cases": bad,
+            "failing_cases": bad, "max_coefficient_error_rel_peak": ce_max,
             "thresholds": {"coefficients": "1e-6 of the spectrum peak (regularisers of full column rank)",
                            "rnorm": "1e-8 relative + 1e-12 (1e-7 without regulariser) of the signal norm",
                            "failing case": "any status / coefficient / rnorm / sentinel disagreement or a negative coefficient"},
