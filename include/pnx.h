@@ -236,7 +236,8 @@ int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg
  *   apply_cutoffs(d, f, cutoffs): per range (lo, hi) no peak -> NaN, one -> kept, several -> geometric_mean_peak
  *     (log10 of the weighted geometric mean position -- the reference's own convention -- and the summed fraction);
  *     fractions renormalised over the ranges.
- *   spectrum (n_vox, n_bins) host|device; bins (n_bins,) host; cutoffs (n_cut, 2) host.
+ *   spectrum (n_vox, n_bins) host|device, 3 <= n_bins <= 512; bins (n_bins,) host (up to 256 bins they travel in the kernel
+ *     arguments, beyond in a stream-ordered device buffer: a device-mode call only enqueues either way); cutoffs (n_cut, 2) host.
  *   n_peaks (n_vox) int32: peaks found (may exceed max_peaks: the first max_peaks <= 64 are reported; a spectrum with more
  *     than 64 peaks -- 16 when it has a flat-topped rise, which takes SciPy's sequential scan on one lane -- gets NaN rows:
  *     its fractions would have to be normalised over peaks the table cannot hold; a 250-bin spectrum has at most 124 maxima);
