@@ -33,7 +33,8 @@ SOURCE_GROUPS = {
     "sweep": ["pnx_sweep.hip"],
     # the host boundary (streamed path, chunk ring, deferred NNLS hand-over, peak tables): host-mode / PCIe-inclusive figures and
     # the host-path fuzz summaries are stamped with this id, so that they are not replayed as current after pnx_api.hip changes
-    "host": ["pnx_api.hip", "pnx_internal.hpp"],
+    # (round 4: the orchestration of both host paths moved into pnx_host_pipeline.hpp; the peak analysis the rings call is pnx_spectrum.hip)
+    "host": ["pnx_api.hip", "pnx_internal.hpp", "pnx_host_pipeline.hpp", "pnx_spectrum.hip"],
 }
 
 
