@@ -181,11 +181,13 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  * limit was 256).  Up to 256 bins a lane of the wavefront that owns a voxel holds four bins, and every fast path is built on
  * that: the block kernel's LDS copy of the basis (32 x 258 doubles = 66 KB; at eight bins per lane 131 KB of a CU's 160 KB, two
  * voxels in flight per CU instead of twelve), the general kernel's 128 registers (sixteen waves per CU), the MFMA Gram step's
- * 256-column product.  257 .. 512 bins run on SEPARATE, SLOWER instantiations with eight bins per lane (a "wide" plan): the
- * Gram-form kernel at 256 registers (eight waves per CU, A^T y on the vector unit, no block kernel, no MFMA step) and the
- * QR-form kernels with a wider dual.  Same algorithm, same decisions, same parity bar (reference fixtures g11_*, oracle
- * tests); measured on the C4 signal with 32 b-values: 2.2 M voxels/s at 300 bins and 1.4 M at 512 with the order-2
- * regulariser (8.6 M at 250: the step at 257 bins is a factor of four), 8.8 M / 7.8 M without (10.5 M at 250).
+ * 256-column product.  257 .. 512 bins run on SEPARATE, SLOWER instantiations (a "wide" plan): the Gram-form kernel with six
+ * (up to 384 bins) or eight bins per lane and the 256 passive-set positions of the narrow kernel (twelve waves per CU, A^T y
+ * on the vector unit, no block kernel, no MFMA step; a voxel whose passive set wants a 257th position is handed to a
+ * 512-position instantiation), and the QR-form kernels with a wider dual.  Same algorithm, same decisions, same parity bar
+ * (reference fixtures g11_*, oracle tests); measured on the C4 signal with 32 b-values: 3.4 M voxels/s at 300 bins, 2.7 M at
+ * 384 and 1.7 M at 512 with the order-2 regulariser (8.6 M at 250: the step at 257 bins is a factor of 2.5), 8.8 M / 7.9 M
+ * without (10.5 M at 250).
  * pnx_nnls_aty_f64 (the MFMA step on its own) stays a 256-column layout and refuses a wide plan.
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;

@@ -41,6 +41,9 @@ namespace pnx {
 #ifndef PNX_NNLS_GBATCH
 #define PNX_NNLS_GBATCH 4
 #endif
+#ifndef PNX_NNLS_W6_WPS
+#define PNX_NNLS_W6_WPS 3  // waves per SIMD of nnls_kernel<6, 4>
+#endif
 #ifndef PNX_NNLS_WAVES_PER_SIMD
 #define PNX_NNLS_WAVES_PER_SIMD 4
 #endif
@@ -73,10 +76,12 @@ struct NnlsArgs {
     int n_meas, n_bins, n_reg, max_iter;
     double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] for |j - i| <= 2 (mu included), zero outside
     int rhb;       // its half bandwidth (1 or 2); 0: general regulariser, rows of RT are used instead
-    const int32_t *redo_list, *redo_count;  // non-null: only the voxels redo_list[0 .. *redo_count) (handed over by pnx_nnls_blk.hip)
+    const int32_t *redo_list, *redo_count;  // non-null: only the voxels redo_list[0 .. *redo_count) (handed over by pnx_nnls_blk.hip, or by <8, 4> to <8, 8>)
+    int32_t *bail;  // <KB, KP < KB> only: [0] number of voxels whose passive set outgrew 64 KP positions, [1 ..] their indices
 };
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
+constexpr int kGenBail = 2;  // internal status of nnls_kernel<KB, KP < KB>: hand the voxel over
 
 // out[s] (k = lane + 64 s) = sum_{i >= k} va_i * M[i][k]  (and the same with vb when TWO): one sweep over the
 // packed lower-triangular M, every row read contiguously; va_i / vb_i are broadcast with v_readlane.
@@ -153,10 +158,12 @@ __device__ inline void col_pass(const double *Mlds, const double *Mg, int p, int
 #define STAMP(k) do {} while (0)
 #endif
 
-// KS: bins (and passive-set positions) per lane -- 4 up to 256 bins, 8 for the wide plans (257 .. 512 bins: twice the position-
-// and bin-indexed registers, two waves per SIMD instead of four, A^T y on the VALU)
-template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES_PER_SIMD : 2) nnls_kernel(const NnlsArgs A) {
-    constexpr int kBS = kW * KS;  // row stride of G, Bp (and of the MFMA product, KS == 4 only)
+// KB: bins per lane, KP: passive-set positions per lane (position i lives in lane i & 63, slot i >> 6).  <4, 4>: up to 256 bins,
+// 16 waves per CU.  Wide plans (257 .. 512 bins, A^T y on the VALU): <8, 4> (<6, 4> up to 384 bins) -- twice the bin-indexed registers (dual, A^T y,
+// passive flags, rows of G) but the position-indexed ones of the narrow kernel, so three waves per SIMD; a voxel whose passive set
+// wants a 257th position is handed to <8, 8> (two waves per SIMD) through the bail list, as the block kernel hands over to <4, 4>.
+template <int KB, int KP> __global__ void __launch_bounds__(64, KB == 4 ? PNX_NNLS_WAVES_PER_SIMD : (KP == 4 ? (KB == 6 ? PNX_NNLS_W6_WPS : 3) : 2)) nnls_kernel(const NnlsArgs A) {
+    constexpr int kBS = KB == 4 ? kNnlsMaxBins : kNnlsWideBins;  // row stride of G, Bp (and of the MFMA product, KB == 4 only); <6, 4> reads 384 bins of 512-bin rows
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -164,7 +171,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
     extern __shared__ double Mlds[];  // packed rows 0..kLdsRows-1 of M, then bc[64]
     double *bc = Mlds + kLdsTri;      // broadcast buffer: position-indexed values of slot 0, read with a uniform address
     const int lane = threadIdx.x;
-    double *Mg = A.Mglob + (size_t)blockIdx.x * glob_tri<KS>();
+    double *Mg = A.Mglob + (size_t)blockIdx.x * glob_tri<KP>();
     gen_lds_double *MldsT = (gen_lds_double *)Mlds;
     gen_glb_double *MgT = (gen_glb_double *)Mg;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
@@ -202,9 +209,9 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
         }
         yn2 = wave_sum(yn2);
         finite = __all(finite ? 1 : 0) != 0;
-        double aty[KS] = {}, w[KS], z[KS] = {};
-        bool inP[KS] = {};
-        if (KS == 4 && finite && A.aty) {
+        double aty[KB] = {}, w[KB], z[KP] = {};
+        bool inP[KB] = {};
+        if (KB == 4 && finite && A.aty) {
             const double *ar = A.aty + (size_t)vox * kBS + 2 * lane;
             const double2 a0 = *reinterpret_cast<const double2 *>(ar);
             const double2 a1 = *reinterpret_cast<const double2 *>(ar + 128);
@@ -217,36 +224,40 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
             for (int k = 0; k < nm; ++k) {
                 const double yk = k < kW ? rl(yreg[0], k & 63) : rl(yreg[1], k & 63);
                 const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
-                double2 bh[KS / 2];
+                double2 bh[KB / 2];
 #pragma unroll
-                for (int h = 0; h < KS / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+                for (int h = 0; h < KB / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
 #pragma unroll
-                for (int h = 0; h < KS / 2; ++h) {
+                for (int h = 0; h < KB / 2; ++h) {
                     aty[2 * h] += bh[h].x * yk;
                     aty[2 * h + 1] += bh[h].y * yk;
                 }
             }
         }
         // position-indexed state
-        double q[KS] = {}, x[KS] = {};
-        int pidx[KS] = {};
+        double q[KP] = {}, x[KP] = {};
+        int pidx[KP] = {};
         int p = 0, iteration = 0, status = finite ? 1 : -2;
         STAMP(0);
 
         while (status == 1 && p < n && p < m_total) {
+            if (KP < KB && p >= kW * KP) {  // every position slot is in use: the <KB, KB> instantiation redoes this voxel
+                status = kGenBail;
+                break;
+            }
             // ---- dual w = A^T y - G[:,P] x_P on the zero set: p rows of G (L2 resident), kGBatch in flight
 #pragma unroll
-            for (int s = 0; s < KS; ++s) w[s] = aty[s];
+            for (int s = 0; s < KB; ++s) w[s] = aty[s];
             // positions 64 sl .. 64 sl + 63 live in register slot sl: one loop per slot keeps the slot index a
             // compile-time constant (a run-time slot select costs ~35 scalar instructions per row)
             bc[lane] = x[0];  // the kernel is VALU-issue bound: x_pos comes back through an LDS broadcast read, not 2 readlanes
 #pragma unroll
-            for (int sl = 0; sl < KS; ++sl) {
+            for (int sl = 0; sl < KP; ++sl) {
                 if (p <= sl * kW) break;  // wave-uniform
                 const int cnt = (p - sl * kW) < kW ? (p - sl * kW) : kW;
                 int l0 = 0;
                 for (; l0 + kGBatch <= cnt; l0 += kGBatch) {  // full batches: no clamping, no masking
-                    double2 gg[kGBatch][KS / 2];
+                    double2 gg[kGBatch][KB / 2];
                     double xs[kGBatch];
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
@@ -254,19 +265,19 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                         xs[u] = sl == 0 ? bc[l0 + u] : rl(x[sl], l0 + u);
                         const double *gc = A.G + (size_t)col * kBS + 2 * lane;
 #pragma unroll
-                        for (int h = 0; h < KS / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
+                        for (int h = 0; h < KB / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
                     }
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
 #pragma unroll
-                        for (int h = 0; h < KS / 2; ++h) {
+                        for (int h = 0; h < KB / 2; ++h) {
                             w[2 * h] -= gg[u][h].x * xs[u];
                             w[2 * h + 1] -= gg[u][h].y * xs[u];
                         }
                     }
                 }
                 if (l0 < cnt) {  // ragged last batch
-                    double2 gg[kGBatch][KS / 2];
+                    double2 gg[kGBatch][KB / 2];
                     double xs[kGBatch];
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
@@ -277,12 +288,12 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                         xs[u] = on ? xv : 0.0;
                         const double *gc = A.G + (size_t)col * kBS + 2 * lane;
 #pragma unroll
-                        for (int h = 0; h < KS / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
+                        for (int h = 0; h < KB / 2; ++h) gg[u][h] = *reinterpret_cast<const double2 *>(gc + 128 * h);
                     }
 #pragma unroll
                     for (int u = 0; u < kGBatch; ++u) {
 #pragma unroll
-                        for (int h = 0; h < KS / 2; ++h) {
+                        for (int h = 0; h < KB / 2; ++h) {
                             w[2 * h] -= gg[u][h].x * xs[u];
                             w[2 * h + 1] -= gg[u][h].y * xs[u];
                         }
@@ -290,42 +301,42 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 }
             }
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KB; ++s)
                 if (inP[s] || binof(lane, s) >= n) w[s] = -INFINITY;
             STAMP(1);
 
             bool accepted = false;
             int jmax = 0;
             double lam = 0, qn = 0, inv_lam = 0;
-            double l[KS];
+            double l[KP];
             for (;;) {
                 // ---- largest positive w_j (ties: lowest bin)
                 double best = -INFINITY;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) best = fmax(best, w[s]);
+                for (int s = 0; s < KB; ++s) best = fmax(best, w[s]);
                 best = wave_max(best);
                 if (!(best > 0)) break;  // KKT satisfied
                 int bj = kNone;
 #pragma unroll
-                for (int s = KS - 1; s >= 0; --s)
+                for (int s = KB - 1; s >= 0; --s)
                     if (w[s] == best) bj = binof(lane, s);
                 jmax = wave_min_i(bj);
                 // ---- g = G[P, jmax] (by position), l = M g
                 const double *grow = A.G + (size_t)jmax * kBS;
-                double g[KS];
+                double g[KP];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) g[s] = (lane + kW * s < p) ? grow[pidx[s]] : 0.0;
+                for (int s = 0; s < KP; ++s) g[s] = (lane + kW * s < p) ? grow[pidx[s]] : 0.0;
                 const double Gjj = grow[jmax];
                 double atyj;
                 {
                     const int ol = (jmax & 127) >> 1, os = ((jmax >> 7) << 1) | (jmax & 1);  // owner lane / slot
-                    double av = aty[KS - 1];
+                    double av = aty[KB - 1];
 #pragma unroll
-                    for (int s = KS - 2; s >= 0; --s) av = os == s ? aty[s] : av;
+                    for (int s = KB - 2; s >= 0; --s) av = os == s ? aty[s] : av;
                     atyj = rl(av, ol);
                 }
 #pragma unroll
-                for (int s = 0; s < KS; ++s) l[s] = 0;
+                for (int s = 0; s < KP; ++s) l[s] = 0;
                 {
                     // LDS rows as a column sweep: uniform k, lane i accumulates M[i][k] g_k for i >= k
                     const int plim = p < kLdsRows ? p : kLdsRows;
@@ -393,11 +404,11 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                             if (lane == ((i + r) & 63)) l[si] = li;
                         }
                     };
-                    for_pos4n<KS>(kLdsRows, p, four, one);
+                    for_pos4n<KP>(kLdsRows, p, four, one);
                 }
                 double ll = 0, lq = 0;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
+                for (int s = 0; s < KP; ++s) {
                     if (lane + kW * s < p) {
                         ll += l[s] * l[s];
                         lq += l[s] * q[s];
@@ -426,7 +437,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 }
                 // reject: w[j] = 0 and look for the next largest
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KB; ++s)
                     if (binof(lane, s) == jmax) w[s] = 0.0;
             }
             STAMP(2);
@@ -440,11 +451,11 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 // one sweep over M gives the new row r = -(l^T M) / lam.  z = M^T q is then a rank-one update of the
                 // current solution (x == z = M_old^T q_old whenever a column enters): z_k = x_k + r_k * qn.  After
                 // every removal z is recomputed from scratch (second sweep below), so nothing drifts.
-                double a1[KS], a2[KS];
-                col_pass<false, KS>(Mlds, Mg, p, lane, l, l, a1, a2);
+                double a1[KP], a2[KP];
+                col_pass<false, KP>(Mlds, Mg, p, lane, l, l, a1, a2);
                 const double inv = inv_lam;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
+                for (int s = 0; s < KP; ++s) {
                     const int k = lane + kW * s;
                     if (k <= p) {
                         const double r = k < p ? -a1[s] * inv : inv;
@@ -454,6 +465,9 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                             MgT[tri(p) - kLdsTri + k] = r;
                         z[s] = k < p ? x[s] + r * qn : qn * inv;
                     }
+                }
+#pragma unroll
+                for (int s = 0; s < KB; ++s) {
                     if (binof(lane, s) == jmax) inP[s] = true;
                 }
                 put(q, p, qn, lane);
@@ -476,10 +490,10 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                     // divisions and two wave reductions
                     bool viol = false;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) viol = viol || (lane + kW * s < p && z[s] <= 0);
+                    for (int s = 0; s < KP; ++s) viol = viol || (lane + kW * s < p && z[s] <= 0);
                     if (!__any(viol ? 1 : 0)) {
 #pragma unroll
-                        for (int s = 0; s < KS; ++s)
+                        for (int s = 0; s < KP; ++s)
                             if (lane + kW * s < p) x[s] = z[s];
                         break;
                     }
@@ -487,7 +501,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 double bestT = INFINITY;
                 int bpos = kNone;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
+                for (int s = 0; s < KP; ++s) {
                     const int i = lane + kW * s;
                     if (i < p && z[s] <= 0) {
                         const double T = -x[s] / (z[s] - x[s]);
@@ -505,13 +519,13 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 }
                 if (bpos == kNone) {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s)
+                    for (int s = 0; s < KP; ++s)
                         if (lane + kW * s < p) x[s] = z[s];
                     break;
                 }
                 const double alpha = bestT;
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KP; ++s)
                     if (lane + kW * s < p) x[s] = x[s] + alpha * (z[s] - x[s]);
                 STAMP(4);
                 int jj = bpos;
@@ -521,10 +535,10 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
 #endif
                     // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
                     // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-                    double mv[KS], pre[KS];
+                    double mv[KP], pre[KP];
                     double carry = 0;
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
+                    for (int s = 0; s < KP; ++s) {
                         const int i = lane + kW * s;
                         mv[s] = 0;
                         pre[s] = carry;
@@ -540,12 +554,12 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                             carry += rl(sc, 63);
                         }
                     }
-                    double mnext[KS], prenext[KS];
+                    double mnext[KP], prenext[KP];
                     shift_down(mv, mnext, lane);
                     shift_down(pre, prenext, lane);
-                    double cs[KS], sn[KS];
+                    double cs[KP], sn[KP];
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
+                    for (int s = 0; s < KP; ++s) {
                         const int i = lane + kW * s;
                         cs[s] = 1.0;
                         sn[s] = 0.0;
@@ -561,9 +575,9 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                     }
                     const int bin_out = get_at_i(pidx, jj);
                     {
-                        double car[KS];
+                        double car[KP];
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) {
+                        for (int s = 0; s < KP; ++s) {
                             const int c = lane + kW * s;
                             car[s] = 0.0;
                             if (c < jj) {
@@ -574,9 +588,9 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                             }
                         }
                         double carq = get_at(q, jj);
-                        double qsh[KS];
+                        double qsh[KP];
                         shift_down(q, qsh, lane);  // qsh[i] = q[i + 1]
-                        for_posn<KS, 2>(jj, p - 1, [&](int i, auto S) {
+                        for_posn<KP, 2>(jj, p - 1, [&](int i, auto S) {
                             constexpr int si = decltype(S)::value;
                             const double c_ = rl(cs[si], i & 63), s_ = rl(sn[si], i & 63);
                             const double qnx = rl(qsh[si], i & 63);
@@ -605,17 +619,20 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                     }
                     // ---- drop position jj from x / pidx
                     {
-                        double xsh[KS];
-                        int psh[KS];
+                        double xsh[KP];
+                        int psh[KP];
                         shift_down(x, xsh, lane);
                         shift_down_i(pidx, psh, lane);
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) {
+                        for (int s = 0; s < KP; ++s) {
                             const int i = lane + kW * s;
                             if (i >= jj && i < p - 1) {
                                 x[s] = xsh[s];
                                 pidx[s] = psh[s];
                             }
+                        }
+#pragma unroll
+                        for (int s = 0; s < KB; ++s) {
                             if (binof(lane, s) == bin_out) inP[s] = false;
                         }
                     }
@@ -624,7 +641,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                     // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
                     int bad = kNone;
 #pragma unroll
-                    for (int s = KS - 1; s >= 0; --s) {
+                    for (int s = KP - 1; s >= 0; --s) {
                         const int i = lane + kW * s;
                         if (i < p && x[s] <= 0) bad = i;
                     }
@@ -635,8 +652,8 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 STAMP(5);
                 // ---- z = M^T q
                 {
-                    double dummy[KS];
-                    col_pass<false, KS>(Mlds, Mg, p, lane, q, q, z, dummy);
+                    double dummy[KP];
+                    col_pass<false, KP>(Mlds, Mg, p, lane, q, q, z, dummy);
                 }
                 STAMP(6);
             }
@@ -647,25 +664,29 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
         // the bin-ordered scratch that turns x by position into x by bin (one scatter instead of p x 14 select instructions)
         // and, for the reference's banded regularisers, carries the stencil R x (the generic loop over rows of RT is p
         // dependent L2 round trips per 64 rows of R: 110 k cycles per voxel, 6 % of the kernel, measured with the stamps)
-        double xb[KS] = {};
+        if (KP < KB && status == kGenBail) {
+            if (lane == 0) A.bail[1 + atomicAdd(A.bail, 1)] = (int32_t)vox;
+            continue;
+        }
+        double xb[KB] = {};
         double rn;
         if (status == 1) {
             wave_sync();
-            double *xbuf = Mlds;  // [2 + 64 KS + 2] <= kLdsTri
-            double tt = 0, dummy[KS];
+            double *xbuf = Mlds;  // [2 + 64 KB + 2] <= kLdsTri
+            double tt = 0, dummy[KB];
             reg_terms<false>(xbuf, A.rc, A.rhb, A.rhb ? nreg : 0, p, lane, x, pidx, dummy, &tt);  // leaves x in bin order in xbuf
 #pragma unroll
-            for (int s = 0; s < KS; ++s) xb[s] = xbuf[2 + binof(lane, s)];
+            for (int s = 0; s < KB; ++s) xb[s] = xbuf[2 + binof(lane, s)];
             wave_sync();
             double acc = 0;
             for (int k = 0; k < nm; ++k) {
                 const double *br = A.Bp + (size_t)k * kBS + 2 * lane;
-                double2 bh[KS / 2];
+                double2 bh[KB / 2];
 #pragma unroll
-                for (int h = 0; h < KS / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
+                for (int h = 0; h < KB / 2; ++h) bh[h] = *reinterpret_cast<const double2 *>(br + 128 * h);
                 double part = bh[0].x * xb[0] + bh[0].y * xb[1];
 #pragma unroll
-                for (int h = 1; h < KS / 2; ++h) {
+                for (int h = 1; h < KB / 2; ++h) {
                     part += bh[h].x * xb[2 * h];
                     part += bh[h].y * xb[2 * h + 1];
                 }
@@ -679,7 +700,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
                 for (int i0 = 0; i0 < nreg; i0 += kW) {
                     const int i = i0 + lane;
                     double r = 0;
-                    for_posn<KS, 4>(0, p, [&](int pos, auto S) {
+                    for_posn<KP, 4>(0, p, [&](int pos, auto S) {
                         constexpr int si = decltype(S)::value;
                         const int b = __builtin_amdgcn_readlane(pidx[si], pos & 63);
                         const double xv = rl(x[si], pos & 63);
@@ -693,7 +714,7 @@ template <int KS> __global__ void __launch_bounds__(64, KS == 4 ? PNX_NNLS_WAVES
             rn = sqrt(yn2);  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
         double *cv = A.coeff + (size_t)vox * n;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 0; s < KB; ++s) {
             const int j = binof(lane, s);
             if (j < n) cv[j] = xb[s];
         }
@@ -882,20 +903,31 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     // persistent grid: as many single-wave workgroups as fit (LDS bound), one scratch slab each
     int occ = 0;
     if (wide) {
-        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
-        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<8>, kW, nnls_lds_bytes()));
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        if (n_bins <= 6 * kW)
+            PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<6, 4>, kW, nnls_lds_bytes()));
+        else
+            PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<8, 4>, kW, nnls_lds_bytes()));
     } else {
-        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
-        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<4>, kW, nnls_lds_bytes()));
+        PNX_HIPN(hipFuncSetAttribute((const void *)nnls_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nnls_lds_bytes()));
+        PNX_HIPN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_kernel<4, 4>, kW, nnls_lds_bytes()));
     }
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
     P->n_waves = occ * cus;
-    P->mglob_stride = wide ? glob_tri<8>() : glob_tri<4>();  // 256 KB / 1 MB per resident wave
+    P->mglob_stride = glob_tri<4>();  // 256 KB per resident wave: rows 48 .. 255 of M (both first-pass kernels keep 256 positions)
     // a block-kernel plan runs this kernel only on the voxels handed over (a quarter of the grid, A^T y on the VALU): a quarter
     // of the slabs, and no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
     if (P->blk) P->n_waves = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
     if (P->qr) P->n_waves = 1;  // a QR-form plan never launches this kernel
     PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * P->mglob_stride * sizeof(double)));
+    if (wide && !P->qr) {  // the hand-over pass of a wide plan (passive sets beyond 256 positions): one wave per CU, 1 MB of slab each
+        P->wide_waves = cus;
+        PNX_HIPN(hipMalloc(&P->Mwide, (size_t)P->wide_waves * glob_tri<8>() * sizeof(double)));
+        P->blk_bail_cap = (size_t)kAtyChunk;
+        PNX_HIPN(hipMalloc(&P->blk_bail, (P->blk_bail_cap + 1) * sizeof(int32_t)));
+    }
     P->mfma_ok = !getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64 && !wide;  // LDS stage of Bp: n_meas * 2 KiB
     if (P->mfma_ok) {
         if (!P->blk) PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
@@ -912,6 +944,7 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
     if (P->Mblk) (void)hipFree(P->Mblk);
+    if (P->Mwide) (void)hipFree(P->Mwide);
     if (P->qr_slab) (void)hipFree(P->qr_slab);
     if (P->blk_bail) (void)hipFree(P->blk_bail);
     if (P->aty) (void)hipFree(P->aty);
@@ -948,6 +981,7 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
         for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
         a.rhb = P->rhb;
         a.redo_list = a.redo_count = nullptr;
+        a.bail = nullptr;
         if (use_mfma) {
             const int kpad = (P->n_meas + 3) & ~3;
             const size_t lds = (size_t)kpad * kNnlsMaxBins * sizeof(double);
@@ -961,10 +995,25 @@ int nnls_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max
         }
         PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
         long long grid = c < P->n_waves ? c : P->n_waves;
-        if (P->bstride == kNnlsWideBins)
-            hipLaunchKernelGGL(nnls_kernel<8>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
-        else
-            hipLaunchKernelGGL(nnls_kernel<4>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+        if (P->bstride == kNnlsWideBins) {
+            // first pass: 256 positions per voxel; the voxels that want more go to the list and through <8, 8> right behind it
+            // (stream order; the count stays on the device: an empty list costs the second launch one queue pull per wave)
+            a.bail = P->blk_bail;
+            PNX_HIPN(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
+            if (P->n_bins <= 6 * kW)
+                hipLaunchKernelGGL((nnls_kernel<6, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+            else
+                hipLaunchKernelGGL((nnls_kernel<8, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
+            PNX_HIPN(hipGetLastError());
+            PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
+            a.bail = nullptr;
+            a.redo_list = P->blk_bail + 1;
+            a.redo_count = P->blk_bail;
+            a.Mglob = P->Mwide;
+            long long g2 = c < P->wide_waves ? c : P->wide_waves;
+            hipLaunchKernelGGL((nnls_kernel<8, 8>), dim3((unsigned)g2), dim3(kW), nnls_lds_bytes(), stream, a);
+        } else
+            hipLaunchKernelGGL((nnls_kernel<4, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);
         PNX_HIPN(hipGetLastError());
     }
     return PNX_OK;
@@ -993,11 +1042,12 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
     a.rhb = P->rhb;
     a.redo_list = list;
     a.redo_count = count;
+    a.bail = nullptr;
     PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
     // the plan's (quartered) persistent grid: with an empty list a wave costs one queue pull
     long long grid = P->n_waves;
     if (grid > n_vox) grid = n_vox;
-    hipLaunchKernelGGL(nnls_kernel<4>, dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);  // block-kernel plans only: never wide
+    hipLaunchKernelGGL((nnls_kernel<4, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);  // block-kernel plans only: never wide
     PNX_HIPN(hipGetLastError());
     return PNX_OK;
 }

@@ -32,8 +32,10 @@ struct NnlsPlanData {
     int qr_slab_groups = 0;
     bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
+    double *Mwide = nullptr;  // wide plans: slabs of the hand-over pass nnls_kernel<8, 8> (rows up to 511), one wave per CU
+    int wide_waves = 0;
     int blk_groups = 0;       // its persistent workgroups (16 waves each)
-    int32_t *blk_bail = nullptr;  // [0]: number of voxels the block kernel handed to the general one (more than 128 passive bins), [1 ..]: their indices
+    int32_t *blk_bail = nullptr;  // [0]: number of voxels the block kernel handed to the general one (more than 128 passive bins), [1 ..]: their indices; a wide plan's nnls_kernel<8, 4> -> <8, 8> list (more than 256)
     size_t blk_bail_cap = 0;      // voxels the list can hold
     unsigned long long *queue = nullptr;
 };

@@ -138,24 +138,28 @@ def test_wide_unregularised_plans_match_oracle(gpu, oracle, n_b, n_bins):
         assert (r["coefficients"] >= 0).all()
 
 
-@pytest.mark.parametrize("dense", [False, True])
-def test_wide_passive_set_beyond_256_positions(gpu, oracle, dense):
-    """A strongly damped fit of a positive combination of ALL 300 columns: every bin enters, the passive set grows through the
-    fifth register slot of the position-indexed vectors of the eight-slot kernel, the overflow rows of the inverse factor reach
-    row 299 of its slab; with a dense (non-Toeplitz) regulariser the generic rows-of-reg epilogue runs too."""
+@pytest.mark.parametrize("dense,n_bins", [(False, 300), (True, 300), (False, 420), (True, 500)])
+def test_wide_passive_set_beyond_256_positions(gpu, oracle, dense, n_bins):
+    """A strongly damped fit of a positive combination of ALL columns: every bin enters.  The first-pass kernels of a wide plan
+    (`nnls_kernel<6, 4>` up to 384 bins, `<8, 4>` beyond) keep 256 positions; at the 257th they hand the voxel over to `<8, 8>`,
+    where the passive set grows through the fifth .. eighth register slot of the position-indexed vectors and the overflow rows
+    of the inverse factor reach row n_bins - 1 of its slab; with a dense (non-Toeplitz) regulariser the generic rows-of-reg
+    epilogue runs too."""
     rng = np.random.default_rng(5)
-    n_b, n_bins = 128, 300
+    n_b = 128
     basis = np.abs(rng.standard_normal((n_b, n_bins)))
     reg = 3.0 * np.eye(n_bins)
     if dense:
         reg = reg + 0.05 * rng.standard_normal((n_bins, n_bins))
-    x_true = rng.uniform(0.5, 2.0, (24, n_bins))
+    x_true = rng.uniform(0.5, 2.0, (48, n_bins))
     x_true[:, ::11] = 0.0
-    y = x_true @ basis.T + 1e-3 * rng.standard_normal((24, n_b))
+    x_true[1::2] *= rng.random((24, n_bins)) < 0.05  # every other voxel: a sparse combination -- stays in the first-pass kernel
+    y = x_true @ basis.T + 1e-3 * rng.standard_normal((48, n_b))
     r = gpu.nnls(basis, reg, y, 2000)
     o = oracle.nnls(basis, reg, y, 2000, n_threads=8)
     np.testing.assert_array_equal(r["status"], o["status"])
-    assert (o["status"] == 1).all() and ((o["coefficients"] > 0).sum(axis=1) > 256).any()
+    support = (o["coefficients"] > 0).sum(axis=1)
+    assert (o["status"] == 1).all() and (support > 256).sum() >= 20 and (support <= 256).sum() >= 10, support
     assert (r["iters"] == o["iters"]).mean() > 0.9
     assert _scaled_err(r["coefficients"], o["coefficients"]).max() < 1e-8
     np.testing.assert_allclose(r["residual"], o["residual"], rtol=1e-9)
