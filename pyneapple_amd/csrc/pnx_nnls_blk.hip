@@ -1262,9 +1262,16 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         }
         PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
     }
-    // launches of kAtyChunk voxels (256 per resident wave keep the drain tail small)
-    for (int64_t off = 0; off < n_vox; off += kAtyChunk) {
-        const int64_t c = (n_vox - off) < kAtyChunk ? (n_vox - off) : kAtyChunk;
+    // ONE launch for the whole call: the kernel needs no per-chunk buffer (A^T y is never formed), and every launch ends in a
+    // drain tail of ~1.4 ms (C4 volume: 488.2 ms in four launches of 2^20 voxels, 484.1 ms in one; PNX_BLK_CHUNK_LOG2 = 20 brings
+    // the launches of kAtyChunk voxels back)
+    int64_t chunk = n_vox;
+    if (const char *t = getenv("PNX_BLK_CHUNK_LOG2")) {
+        const int l2 = atoi(t);
+        if (l2 >= 10 && l2 <= 30) chunk = (int64_t)1 << l2;
+    }
+    for (int64_t off = 0; off < n_vox; off += chunk) {
+        const int64_t c = (n_vox - off) < chunk ? (n_vox - off) : chunk;
         BlkArgs a;
         a.y = y_d + (size_t)off * P->n_meas;
         a.coeff = coeff_d + (size_t)off * P->n_bins;
