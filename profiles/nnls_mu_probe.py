@@ -37,4 +37,5 @@ for order, mu in cases:
         if no_blk:
             env["PNX_NNLS_NO_BLK"] = "1"
         r = subprocess.run([sys.executable, "-c", CHILD % (HERE, int(order), float(mu), n)], env=env, capture_output=True, text=True)
-        print(f"order={order} mu={mu} {'gram-form only' if no_blk else 'block plan   '}", r.stdout.strip() or r.stderr[-1200:], flush=True)
+        pilot = [l for l in r.stderr.splitlines() if "pnx nnls pilot" in l]
+        print(f"order={order} mu={mu} {'gram-form only' if no_blk else 'block plan   '}", r.stdout.strip() or r.stderr[-1200:], pilot[0] if pilot else "", flush=True)

@@ -78,6 +78,7 @@ struct NnlsArgs {
     int rhb;       // its half bandwidth (1 or 2); 0: general regulariser, rows of RT are used instead
     const int32_t *redo_list, *redo_count;  // non-null: only the voxels redo_list[0 .. *redo_count) (handed over by pnx_nnls_blk.hip, or by <8, 4> to <8, 8>)
     int32_t *bail;  // <KB, KP < KB> only: [0] number of voxels whose passive set outgrew 64 KP positions, [1 ..] their indices
+    const int32_t *route = nullptr;  // non-null: the launch only runs when *route == 1 (the pilot of a block-kernel plan chose the Gram form, pnx_nnls_blk.hip)
 };
 
 __device__ inline int tri(int i) { return i * (i + 1) / 2; }
@@ -176,6 +177,7 @@ template <int KB, int KP> __global__ void __launch_bounds__(64, KB == 4 ? PNX_NN
     gen_glb_double *MgT = (gen_glb_double *)Mg;
     const int n = A.n_bins, nm = A.n_meas, nreg = A.n_reg;
     const int m_total = nm + nreg;
+    if (A.route && *A.route != 1) return;  // wave uniform: the pilot kept the block kernel, nothing to do here
 
     for (;;) {
         unsigned long long vq = 0;
@@ -917,9 +919,9 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls kernel does not fit on a CU");
     P->n_waves = occ * cus;
     P->mglob_stride = glob_tri<4>();  // 256 KB per resident wave: rows 48 .. 255 of M (both first-pass kernels keep 256 positions)
-    // a block-kernel plan runs this kernel only on the voxels handed over (a quarter of the grid, A^T y on the VALU): a quarter
-    // of the slabs, and no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
-    if (P->blk) P->n_waves = P->n_waves / 4 > 0 ? P->n_waves / 4 : 1;
+    // a block-kernel plan runs this kernel on the voxels handed over and, when the pilot of a call finds that too many are (strong
+    // regularisers: supports beyond 128 bins), on the whole call (A^T y on the VALU either way): the full grid of slabs (1 GB),
+    // but no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
     if (P->qr) P->n_waves = 1;  // a QR-form plan never launches this kernel
     PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * P->mglob_stride * sizeof(double)));
     if (wide && !P->qr) {  // the hand-over pass of a wide plan (passive sets beyond 256 positions): one wave per CU, 1 MB of slab each
@@ -947,6 +949,7 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->Mwide) (void)hipFree(P->Mwide);
     if (P->qr_slab) (void)hipFree(P->qr_slab);
     if (P->blk_bail) (void)hipFree(P->blk_bail);
+    if (P->route) (void)hipFree(P->route);
     if (P->aty) (void)hipFree(P->aty);
     if (P->queue) (void)hipFree(P->queue);
     *P = NnlsPlanData();
@@ -1044,7 +1047,39 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
     a.redo_count = count;
     a.bail = nullptr;
     PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-    // the plan's (quartered) persistent grid: with an empty list a wave costs one queue pull
+    // the plan's persistent grid: with an empty list a wave costs one queue pull
+    long long grid = P->n_waves;
+    if (grid > n_vox) grid = n_vox;
+    hipLaunchKernelGGL((nnls_kernel<4, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);  // block-kernel plans only: never wide
+    PNX_HIPN(hipGetLastError());
+    return PNX_OK;
+}
+
+int nnls_routed_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                       int8_t *status_d, int32_t *iters_d, const int32_t *route, hipStream_t stream) {
+    NnlsArgs a;
+    a.y = y_d;
+    a.coeff = coeff_d;
+    a.rnorm = rnorm_d;
+    a.status = status_d;
+    a.iters = iters_d;
+    a.G = P->G;
+    a.Bp = P->Bp;
+    a.RT = P->RT;
+    a.aty = nullptr;
+    a.Mglob = P->Mglob;
+    a.queue = P->queue;
+    a.n_vox = n_vox;
+    a.n_meas = P->n_meas;
+    a.n_bins = P->n_bins;
+    a.n_reg = P->n_reg;
+    a.max_iter = max_iter;
+    for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+    a.rhb = P->rhb;
+    a.redo_list = a.redo_count = nullptr;
+    a.bail = nullptr;
+    a.route = route;
+    PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
     long long grid = P->n_waves;
     if (grid > n_vox) grid = n_vox;
     hipLaunchKernelGGL((nnls_kernel<4, 4>), dim3((unsigned)grid), dim3(kW), nnls_lds_bytes(), stream, a);  // block-kernel plans only: never wide

@@ -37,6 +37,7 @@ struct NnlsPlanData {
     int blk_groups = 0;       // its persistent workgroups (16 waves each)
     int32_t *blk_bail = nullptr;  // [0]: number of voxels the block kernel handed to the general one (more than 128 passive bins), [1 ..]: their indices; a wide plan's nnls_kernel<8, 4> -> <8, 8> list (more than 256)
     size_t blk_bail_cap = 0;      // voxels the list can hold
+    int32_t *route = nullptr;     // block-kernel plans: [0] the route the pilot of the current call chose (0: block kernel, 1: Gram-form kernel), device
     unsigned long long *queue = nullptr;
 };
 
@@ -50,6 +51,9 @@ int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int 
 // the general kernel on the voxels list[0 .. *count) of a chunk (A^T y on the VALU)
 int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                      int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream);
+// the general kernel on ALL n_vox voxels (A^T y on the VALU) -- unless *route != 1 when it starts: then every wave leaves at once
+int nnls_routed_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                       int8_t *status_d, int32_t *iters_d, const int32_t *route, hipStream_t stream);
 bool nnls_blk_applicable(const NnlsPlanData *P);
 int nnls_blk_plan_init(NnlsPlanData *P);
 // Deferred hand-over (host-array calls made of several chunks, pnx_api.hip): the block kernel appends the voxels it hands over

@@ -92,6 +92,7 @@ struct BlkArgs {
     double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] (mu included)
     int rhb;       // half bandwidth, 1 or 2
     int test_rej_k, test_rej_n;  // test hook (PNX_NNLS_TEST_REJECT=k,n): with p % k == k - 1 the first n candidates of an outer iteration are rejected unseen
+    const int32_t *route;  // non-null: the launch only runs while *route == 0 (the pilot of the call kept the block kernel)
 };
 
 // -DPNX_NNLS_BLK_CHECK: every index into the slab of M / a row of G is range checked; the first violation is reported with
@@ -799,6 +800,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
     long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // voxels, outer iterations, rejected candidates, removals, rotated rows, sum of p at the dual, appends with p > 48, p > 64
 #endif
     extern __shared__ double dyn_lds[];
+    if (kargs()->route && *kargs()->route != 0) return;  // uniform over the grid: the pilot of this call chose the Gram-form kernel
     const int lane = threadIdx.x & (kW - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = kargs()->n_bins, nm = kargs()->n_meas, nreg = kargs()->n_reg;
@@ -1233,6 +1235,8 @@ int nnls_blk_plan_init(NnlsPlanData *P) {
     PNX_HIPB(hipMemset(P->Mblk, 0, bytes));
     P->blk_bail_cap = (size_t)kAtyChunk;
     PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));  // [0]: count, [1 ..]: voxel indices
+    PNX_HIPB(hipMalloc(&P->route, sizeof(int32_t)));
+    PNX_HIPB(hipMemset(P->route, 0, sizeof(int32_t)));
     return PNX_OK;
 }
 
@@ -1249,6 +1253,18 @@ __global__ void __launch_bounds__(256) bail_gather_kernel(int32_t *counters, con
     if (threadIdx.x == 0 && n > p) counters[1] = n;
 }
 
+// The pilot of a call.  This kernel pays for every voxel it hands over twice: ~130 outer iterations here, then the whole solve
+// again in the Gram-form kernel.  At the reference's regularisation strength one voxel in 10^4 is handed over; with a stronger
+// regulariser (order 1 with mu = 0.5: half of them) the plan was up to twice as slow as the Gram-form kernel alone
+// (profiles/nnls_mu_probe.py).  So a call of at least 4 kBlkPilot voxels solves its first kBlkPilot voxels here, and what that
+// pilot hands over decides the route of the rest ON THE DEVICE: both kernels are launched over the remaining voxels, and the
+// one that was not chosen leaves at once (one scalar load per wave).  The choice depends on the pilot's voxels only, never on
+// timing: the same call takes the same route every time.
+constexpr int64_t kBlkPilot = 12288;  // four voxels per resident wave of a full grid
+__global__ void blk_route_kernel(const int32_t *n_bail, int pilot, int permille, int32_t *route) {
+    route[0] = ((long long)n_bail[0] * 1000 > (long long)permille * pilot) ? 1 : 0;
+}
+
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                           int8_t *status_d, int32_t *iters_d, hipStream_t stream, const NnlsDefer *defer) {
     if (n_vox <= 0) return PNX_OK;
@@ -1262,16 +1278,24 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         }
         PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
     }
-    // ONE launch for the whole call: the kernel needs no per-chunk buffer (A^T y is never formed), and every launch ends in a
-    // drain tail of ~1.4 ms (C4 volume: 488.2 ms in four launches of 2^20 voxels, 484.1 ms in one; PNX_BLK_CHUNK_LOG2 = 20 brings
-    // the launches of kAtyChunk voxels back)
+    // ONE launch for the rest of the call: the kernel needs no per-chunk buffer (A^T y is never formed), and every launch ends in
+    // a drain tail of ~1.4 ms (C4 volume: 488.2 ms in four launches of 2^20 voxels, 484.1 ms in one; PNX_BLK_CHUNK_LOG2 = 20
+    // brings the launches of kAtyChunk voxels back)
     int64_t chunk = n_vox;
     if (const char *t = getenv("PNX_BLK_CHUNK_LOG2")) {
         const int l2 = atoi(t);
         if (l2 >= 10 && l2 <= 30) chunk = (int64_t)1 << l2;
     }
-    for (int64_t off = 0; off < n_vox; off += chunk) {
-        const int64_t c = (n_vox - off) < chunk ? (n_vox - off) : chunk;
+    // the pilot (see blk_route_kernel): in the first chunk of a call; the later chunks of a host-array call follow its route
+    // (they run on the same stream, behind it)
+    int permille = 300;  // with the full grid behind the hand-over pass the block kernel wins up to ~30 % (profiles/nnls_mu_probe.py)
+    if (const char *t = getenv("PNX_BLK_ROUTE_PERMILLE")) permille = atoi(t);  // <= 0: no pilot, the block kernel for everything
+    const bool first = !defer || defer->base == 0;
+    const int64_t pilot = (permille > 0 && first && n_vox >= 4 * kBlkPilot) ? kBlkPilot : 0;
+    const int32_t *route = nullptr;
+    if (permille > 0 && defer && first && !pilot) PNX_HIPB(hipMemsetAsync(P->route, 0, sizeof(int32_t), stream));  // a short first chunk: the block kernel
+    if (permille > 0 && (pilot || (defer && !first))) route = P->route;
+    auto launch = [&](int64_t off, int64_t c, const int32_t *rt) -> int {
         BlkArgs a;
         a.y = y_d + (size_t)off * P->n_meas;
         a.coeff = coeff_d + (size_t)off * P->n_bins;
@@ -1296,11 +1320,37 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         if (const char *t = getenv("PNX_NNLS_TEST_REJECT")) {
             if (sscanf(t, "%d,%d", &a.test_rej_k, &a.test_rej_n) != 2 || a.test_rej_k < 1 || a.test_rej_n < 1) a.test_rej_k = a.test_rej_n = 0;
         }
+        a.route = rt;
         PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
         long long grid = (c + kBlkWaves - 1) / kBlkWaves;
         if (grid > P->blk_groups) grid = P->blk_groups;
         hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
         PNX_HIPB(hipGetLastError());
+        return PNX_OK;
+    };
+    if (pilot) {
+        int r = launch(0, pilot, nullptr);
+        if (r) return r;
+        hipLaunchKernelGGL(blk_route_kernel, dim3(1), dim3(1), 0, stream, defer ? defer->counters : P->blk_bail, (int)pilot, permille, P->route);
+        PNX_HIPB(hipGetLastError());
+        if (getenv("PNX_BLK_ROUTE_DEBUG")) {  // diagnostic (synchronises): what the pilot saw
+            int32_t cnt = 0, rt = 0;
+            PNX_HIPB(hipStreamSynchronize(stream));
+            PNX_HIPB(hipMemcpy(&cnt, defer ? defer->counters : P->blk_bail, sizeof(cnt), hipMemcpyDeviceToHost));
+            PNX_HIPB(hipMemcpy(&rt, P->route, sizeof(rt), hipMemcpyDeviceToHost));
+            fprintf(stderr, "pnx nnls pilot: %d of %d voxels handed over (%.1f %%), threshold %.1f %% -> %s\n", cnt, (int)pilot, 100.0 * cnt / (double)pilot,
+                    permille / 10.0, rt ? "Gram-form kernel" : "block kernel");
+        }
+    }
+    for (int64_t off = pilot; off < n_vox; off += chunk) {
+        const int64_t c = (n_vox - off) < chunk ? (n_vox - off) : chunk;
+        int r = launch(off, c, route);
+        if (r) return r;
+    }
+    if (route) {  // the same voxels through the Gram-form kernel -- which leaves at once unless the pilot chose it
+        int r = nnls_routed_device(P, n_vox - pilot, y_d + (size_t)pilot * P->n_meas, max_iter, coeff_d + (size_t)pilot * P->n_bins, rnorm_d + pilot,
+                                   status_d ? status_d + pilot : nullptr, iters_d ? iters_d + pilot : nullptr, route, stream);
+        if (r) return r;
     }
     // voxels whose passive set outgrew this kernel (about one in 10^4 on the reference workload, and the slowest ones: a single
     // launch for the whole call, so that their long solves overlap): the general kernel, from scratch

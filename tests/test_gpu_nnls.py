@@ -447,3 +447,80 @@ def test_wide_plan_through_every_host_path(gpu, oracle, monkeypatch):
             p2.aty_device(16, yd[:16], None, torch.cuda.current_stream().cuda_stream)
         finally:
             p2.close()
+
+
+def _strong_regulariser():
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, reg_order=1, mu=1.0)  # supports beyond 128 bins on more than half of the voxels
+    _, basis, reg = synth.nnls_matrices(32, cfg)
+    return basis, reg
+
+
+def test_pilot_routes_a_strong_regulariser_to_the_gram_form_kernel(gpu, oracle, monkeypatch, capfd):
+    """The block kernel pays twice for a voxel it hands over (passive set beyond 128 positions).  A call of >= 4 x 12 288 voxels
+    therefore solves a pilot of 12 288 first, and when more than 30 % of those are handed over the rest of the call goes to the
+    Gram-form kernel directly -- decided on the device, from the pilot's voxels only.  Same results as the block kernel for
+    everything (PNX_BLK_ROUTE_PERMILLE=0) and as the oracle; the reference's own regulariser stays on the block kernel."""
+    from pyneapple_amd import synth
+
+    basis, reg = _strong_regulariser()
+    _, y, _ = synth.make_numpy("tri_reduced", 4 * 12288 + 777, 32, sigma=0.01, seed=11, scale=1000.0)
+    monkeypatch.setenv("PNX_BLK_ROUTE_DEBUG", "1")
+    capfd.readouterr()
+    routed = gpu.nnls(basis, reg, y, 250)
+    err = capfd.readouterr().err
+    assert "pnx nnls pilot" in err and "-> Gram-form kernel" in err, err
+    monkeypatch.setenv("PNX_BLK_ROUTE_PERMILLE", "0")
+    blk = gpu.nnls(basis, reg, y, 250)
+    assert "pnx nnls pilot" not in capfd.readouterr().err
+    monkeypatch.delenv("PNX_BLK_ROUTE_PERMILLE")
+    np.testing.assert_array_equal(routed["status"], blk["status"])
+    ok = blk["status"] == 1
+    assert _scaled_err(routed["coefficients"][ok], blk["coefficients"][ok]).max() < 1e-9
+    np.testing.assert_allclose(routed["residual"], blk["residual"], rtol=1e-12)
+    assert (routed["iters"] == blk["iters"]).mean() > 0.999
+    # pilot voxels and routed voxels against the oracle
+    pick = np.r_[0:768, 12288:12288 + 768, y.shape[0] - 512:y.shape[0]]
+    o = oracle.nnls(basis, reg, y[pick], 250, n_threads=8)
+    np.testing.assert_array_equal(routed["status"][pick], o["status"])
+    oko = o["status"] == 1
+    assert _scaled_err(routed["coefficients"][pick][oko], o["coefficients"][oko]).max() < 1e-6
+    assert (routed["iters"][pick] == o["iters"]).mean() > 0.99
+    # the same call twice: the route depends on the pilot's voxels only
+    again = gpu.nnls(basis, reg, y, 250)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(again[k], routed[k], err_msg=k)
+    # the reference's regulariser: the pilot keeps the block kernel
+    _, basis2, reg2 = synth.nnls_matrices(32)
+    capfd.readouterr()
+    gpu.nnls(basis2, reg2, y, 250)
+    err = capfd.readouterr().err
+    assert "-> block kernel" in err, err
+
+
+def test_pilot_route_holds_for_the_later_chunks_of_a_host_call(gpu, monkeypatch, capfd):
+    """Host arrays in several chunks: the first chunk runs the pilot, the later ones follow its route (same stream, behind it);
+    the pilot's handed-over voxels go through the deferred pass.  Same bits as the single-chunk call."""
+    from pyneapple_amd import synth
+
+    basis, reg = _strong_regulariser()
+    _, y, _ = synth.make_numpy("tri_reduced", 130000, 32, sigma=0.01, seed=12, scale=1000.0)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    one = plan.solve(y, 250)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "50000")  # three chunks: pilot in the first
+    monkeypatch.setenv("PNX_BLK_ROUTE_DEBUG", "1")
+    capfd.readouterr()
+    many = plan.solve(y, 250)
+    err = capfd.readouterr().err
+    assert err.count("pnx nnls pilot") == 1 and "-> Gram-form kernel" in err, err
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many[k], one[k], err_msg=k)
+    many32 = plan.solve(y.astype(np.float32), 250)
+    one32 = None
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    one32 = plan.solve(y.astype(np.float32), 250)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many32[k], one32[k], err_msg=f"{k} float32")
+    plan.close()
