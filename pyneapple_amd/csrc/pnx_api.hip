@@ -1164,26 +1164,45 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         int32_t cnt[2] = {0, 0};
         PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
         const int n = cnt[0];
-        if (n > defer_cap) return kDeferOverflow;  // more handed-over voxels than the side buffer holds: run again, one pass per chunk
         if (n == 0) return PNX_OK;
-        double *sc = d_sc, *sr = d_sr;
-        int8_t *ss = d_ss;
-        int32_t *si = d_si;
-        std::vector<int32_t> where((size_t)n), hi((size_t)n);
-        std::vector<double> hc((size_t)n * P.n_bins), hr((size_t)n);
-        std::vector<int8_t> hs((size_t)n);
-        PNX_HIP(hipMemcpy(hc.data(), sc, hc.size() * sizeof(double), hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hr.data(), sr, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hs.data(), ss, hs.size(), hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hi.data(), si, hi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (n < 0 || (size_t)n > nv) return set_error(PNX_ERR_HIP, "deferred hand-over: %d voxels counted in a call of %zu", n, nv);
+        // More handed-over voxels than the side buffer holds (stronger regularisers than the reference's: a few per cent of the
+        // voxels): the pass behind the last chunk has solved the first defer_cap of them; the others follow in batches of
+        // defer_cap, their signal rows gathered from the caller's array.  (Up to round 4 the whole call ran again.)
+        std::vector<int32_t> where((size_t)n);
         PNX_HIP(hipMemcpy(where.data(), dctx.bail, where.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) {  // (T) of a double rounds to nearest, as the device's narrowing copy does
-            const size_t v = (size_t)where[(size_t)i];
-            if (where[(size_t)i] < 0 || v >= nv) return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[(size_t)i], nv);
-            for (int j = 0; j < P.n_bins; ++j) coeff[v * P.n_bins + j] = (T)hc[(size_t)i * P.n_bins + j];
-            rnorm[v] = (T)hr[(size_t)i];
-            if (status) status[v] = hs[(size_t)i];
-            if (iters) iters[v] = hi[(size_t)i];
+        for (int i = 0; i < n; ++i)
+            if (where[(size_t)i] < 0 || (size_t)where[(size_t)i] >= nv)
+                return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[(size_t)i], nv);
+        const int batch = n < defer_cap ? n : defer_cap;
+        std::vector<int32_t> hi((size_t)batch);
+        std::vector<double> hc((size_t)batch * P.n_bins), hr((size_t)batch), rows;
+        std::vector<int8_t> hs((size_t)batch);
+        for (int b0 = 0; b0 < n; b0 += defer_cap) {
+            const int nb = (n - b0) < defer_cap ? (n - b0) : defer_cap;
+            if (b0 > 0) {
+                rows.resize((size_t)nb * P.n_meas);
+                for (int i = 0; i < nb; ++i) {
+                    const T *src = y + (size_t)where[(size_t)(b0 + i)] * P.n_meas;
+                    for (int j = 0; j < P.n_meas; ++j) rows[(size_t)i * P.n_meas + j] = (double)src[j];
+                }
+                PNX_HIP(hipMemcpy(dctx.y_side, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+                // the list is 0 .. nb - 1 (d_iota) and the count on the device is n >= nb: the kernel stops at the nb it is given
+                int rr = nnls_redo_device(&P, nb, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+                if (rr) return rr;
+                PNX_HIP(hipStreamSynchronize(side.s));
+            }
+            PNX_HIP(hipMemcpy(hc.data(), d_sc, (size_t)nb * P.n_bins * sizeof(double), hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hr.data(), d_sr, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hs.data(), d_ss, (size_t)nb, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hi.data(), d_si, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nb; ++i) {  // (T) of a double rounds to nearest, as the device's narrowing copy does
+                const size_t v = (size_t)where[(size_t)(b0 + i)];
+                for (int j = 0; j < P.n_bins; ++j) coeff[v * P.n_bins + j] = (T)hc[(size_t)i * P.n_bins + j];
+                rnorm[v] = (T)hr[(size_t)i];
+                if (status) status[v] = hs[(size_t)i];
+                if (iters) iters[v] = hi[(size_t)i];
+            }
         }
         return PNX_OK;
     };

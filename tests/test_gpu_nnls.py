@@ -333,7 +333,7 @@ def test_host_chunks_defer_the_hand_over_pass(gpu, monkeypatch):
     assert handed_over.size >= 1  # the sample holds such voxels (tests/test_gpu_parity_large.py compares them with the oracle)
     one32 = plan.solve(y.astype(np.float32), 250)
     monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "3000")  # six ragged chunks
-    for cap in ("16384", "0", str(max(1, handed_over.size - 1))):
+    for cap in ("16384", "0", str(max(1, handed_over.size - 1)), "1"):  # the last two: more voxels than the side buffer holds -> batches
         monkeypatch.setenv("PNX_NNLS_DEFER_CAP", cap)
         many = plan.solve(y, 250)
         for k in ("coefficients", "residual", "status", "iters"):
@@ -519,6 +519,37 @@ def test_pilot_route_holds_for_the_later_chunks_of_a_host_call(gpu, monkeypatch,
         np.testing.assert_array_equal(many[k], one[k], err_msg=k)
     many32 = plan.solve(y.astype(np.float32), 250)
     one32 = None
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    one32 = plan.solve(y.astype(np.float32), 250)
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many32[k], one32[k], err_msg=f"{k} float32")
+    plan.close()
+
+
+def test_many_handed_over_voxels_go_through_the_side_buffer_in_batches(gpu, monkeypatch, capfd):
+    """A regulariser five to ten times the reference's: several per cent of the voxels are handed over, more than the deferred
+    pass's side buffer holds.  The first batch is solved behind the last chunk, the others follow from the caller's array --
+    the call does not run again, and the bits are those of the single-chunk call."""
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, reg_order=2, mu=0.2)
+    _, basis, reg = synth.nnls_matrices(32, cfg)
+    _, y, _ = synth.make_numpy("tri_reduced", 110000, 32, sigma=0.01, seed=13, scale=1000.0)
+    plan = gpu.NnlsPlan(basis, reg, 0)
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
+    monkeypatch.setenv("PNX_BLK_ROUTE_DEBUG", "1")
+    capfd.readouterr()
+    one = plan.solve(y, 250)
+    assert "-> block kernel" in capfd.readouterr().err  # 5 - 10 % handed over: below the pilot's threshold
+    n_over = int(((one["coefficients"] > 0).sum(axis=1) > 128).sum())
+    assert n_over > 3000
+    monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "50000")
+    monkeypatch.setenv("PNX_NNLS_DEFER_CAP", "2048")
+    many = plan.solve(y, 250)
+    assert capfd.readouterr().err.count("pnx nnls pilot") == 1  # one pass over the chunks
+    for k in ("coefficients", "residual", "status", "iters"):
+        np.testing.assert_array_equal(many[k], one[k], err_msg=k)
+    many32 = plan.solve(y.astype(np.float32), 250)
     monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", str(1 << 20))
     one32 = plan.solve(y.astype(np.float32), 250)
     for k in ("coefficients", "residual", "status", "iters"):
