@@ -1051,7 +1051,6 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     // number (they are the longest solves there are): with several chunks the hand-over is deferred -- the chunks only
     // collect the voxels' indices and signal rows, ONE pass at the end of the call solves them, and their rows are patched
     // into the caller's arrays (C4 from numpy arrays: seven passes -> one).
-    constexpr int kDeferOverflow = -1001;
     const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
     const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
     DevBuf dslab;
@@ -1207,7 +1206,6 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         return PNX_OK;
     };
     rc = run(can_defer);
-    if (rc == kDeferOverflow) rc = run(false);
     return rc;
 }
 
@@ -1273,7 +1271,6 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
         return pnx_nnls_spectrum_peaks_f64((int64_t)n, P.n_bins, o.spec, bins_host, height, regularized, rel_height, max_peaks, o.np, o.d,
                                            o.f, n_cut, cutoffs_host, o.dc, o.fc, PNX_MEM_DEVICE, P.device, s);
     };
-    constexpr int kDeferOverflow = -1001;
     const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
     const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
     DevBuf dslab;
@@ -1355,9 +1352,10 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
         if (r || !defer) return r;
         int32_t cnt[2] = {0, 0};
         PNX_HIP(hipMemcpy(cnt, dctx.counters, sizeof(cnt), hipMemcpyDeviceToHost));
-        const size_t n = (size_t)cnt[0];
-        if ((int)n > defer_cap) return kDeferOverflow;
-        if (n == 0) return PNX_OK;
+        if (cnt[0] == 0) return PNX_OK;
+        if (cnt[0] < 0 || (size_t)cnt[0] > nv) return set_error(PNX_ERR_HIP, "deferred hand-over: %d voxels counted in a call of %zu", cnt[0], nv);
+        const size_t n_all = (size_t)cnt[0];
+        const size_t n = n_all < (size_t)defer_cap ? n_all : (size_t)defer_cap;  // voxels per batch: what the side buffer holds
         DevBuf side;
         Out o;
         int32_t *iota = nullptr;
@@ -1368,43 +1366,57 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
             iota = (int32_t *)c.take(n * 4);
             if (pass == 0 && (r = side.alloc(c.off))) return r;
         }
-        std::vector<int32_t> idx(n), where(n), hi(n), hn(n);
+        std::vector<int32_t> idx(n), where(n_all), hi(n), hn(n);
         for (size_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
         PNX_HIP(hipMemcpy(iota, idx.data(), n * 4, hipMemcpyHostToDevice));
-        if ((r = nnls_redo_device(&P, (int64_t)n, dctx.y_side, max_iter, o.spec, o.r, o.s, o.i, iota, dctx.counters, st))) return r;
-        if ((r = analyse(n, o, st))) return r;
-        PNX_HIP(hipStreamSynchronize(st));
-        std::vector<double> hr(n), hd(n * mp), hf(n * mp), hdc(n * nc), hfc(n * nc);
+        PNX_HIP(hipMemcpy(where.data(), dctx.bail, n_all * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n_all; ++i)
+            if (where[i] < 0 || (size_t)where[i] >= nv)
+                return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[i], nv);
+        std::vector<double> hr(n), hd(n * mp), hf(n * mp), hdc(n * nc), hfc(n * nc), rows;
         std::vector<int8_t> hs(n);
-        PNX_HIP(hipMemcpy(hr.data(), o.r, n * 8, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hs.data(), o.s, n, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hi.data(), o.i, n * 4, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hn.data(), o.np, n * 4, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hd.data(), o.d, n * mp * 8, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hf.data(), o.f, n * mp * 8, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hdc.data(), o.dc, n * nc * 8, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(hfc.data(), o.fc, n * nc * 8, hipMemcpyDeviceToHost));
-        PNX_HIP(hipMemcpy(where.data(), dctx.bail, n * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            const size_t v = (size_t)where[i];
-            if (where[i] < 0 || v >= nv) return set_error(PNX_ERR_HIP, "deferred hand-over: voxel index %d outside the call's %zu voxels", where[i], nv);
-            rnorm[v] = hr[i];
-            if (status) status[v] = hs[i];
-            if (iters) iters[v] = hi[i];
-            if (n_peaks) n_peaks[v] = hn[i];
-            for (int j = 0; j < max_peaks; ++j) {
-                d_values[v * max_peaks + j] = hd[i * mp + j];
-                f_values[v * max_peaks + j] = hf[i * mp + j];
+        // the side buffer holds the signal rows of the first batch (gathered chunk by chunk on the device); the rows of the
+        // later ones come from the caller's array
+        for (size_t b0 = 0; b0 < n_all; b0 += n) {
+            const size_t nb = (n_all - b0) < n ? (n_all - b0) : n;
+            if (b0 > 0) {
+                rows.resize(nb * (size_t)P.n_meas);
+                for (size_t i = 0; i < nb; ++i) {
+                    const double *src = y + (size_t)where[b0 + i] * P.n_meas;
+                    for (int j = 0; j < P.n_meas; ++j) rows[i * P.n_meas + j] = src[j];
+                }
+                PNX_HIP(hipMemcpy(dctx.y_side, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
             }
-            for (int j = 0; j < n_cut; ++j) {
-                d_cut[v * n_cut + j] = hdc[i * nc + j];
-                f_cut[v * n_cut + j] = hfc[i * nc + j];
+            if ((r = nnls_redo_device(&P, (int64_t)nb, dctx.y_side, max_iter, o.spec, o.r, o.s, o.i, iota, dctx.counters, st))) return r;
+            if ((r = analyse(nb, o, st))) return r;
+            PNX_HIP(hipStreamSynchronize(st));
+            PNX_HIP(hipMemcpy(hr.data(), o.r, nb * 8, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hs.data(), o.s, nb, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hi.data(), o.i, nb * 4, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hn.data(), o.np, nb * 4, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hd.data(), o.d, nb * mp * 8, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hf.data(), o.f, nb * mp * 8, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hdc.data(), o.dc, nb * nc * 8, hipMemcpyDeviceToHost));
+            PNX_HIP(hipMemcpy(hfc.data(), o.fc, nb * nc * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nb; ++i) {
+                const size_t v = (size_t)where[b0 + i];
+                rnorm[v] = hr[i];
+                if (status) status[v] = hs[i];
+                if (iters) iters[v] = hi[i];
+                if (n_peaks) n_peaks[v] = hn[i];
+                for (int j = 0; j < max_peaks; ++j) {
+                    d_values[v * max_peaks + j] = hd[i * mp + j];
+                    f_values[v * max_peaks + j] = hf[i * mp + j];
+                }
+                for (int j = 0; j < n_cut; ++j) {
+                    d_cut[v * n_cut + j] = hdc[i * nc + j];
+                    f_cut[v * n_cut + j] = hfc[i * nc + j];
+                }
             }
         }
         return PNX_OK;
     };
     rc = run(can_defer);
-    if (rc == kDeferOverflow) rc = run(false);
     return rc;
 }
 

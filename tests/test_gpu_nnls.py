@@ -369,7 +369,7 @@ def test_peak_tables_from_host_arrays_in_chunks(gpu, monkeypatch):
         np.testing.assert_array_equal(one[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(one["residual"], full["residual"])
     monkeypatch.setenv("PNX_NNLS_PEAKS_CHUNK", "3000")
-    for cap, ring in (("16384", "1"), ("0", "1"), ("16384", "0")):
+    for cap, ring in (("16384", "1"), ("0", "1"), ("16384", "0"), ("1", "1")):  # the last: one handed-over voxel per batch
         monkeypatch.setenv("PNX_NNLS_DEFER_CAP", cap)
         monkeypatch.setenv("PNX_NNLS_PEAKS_RING", ring)
         many = plan.solve_peaks(y, bins, **kw)
