@@ -44,7 +44,10 @@ def test_fd_matches_reference_golden_g7(gpu, name):
 
 
 @pytest.mark.parametrize("model,n_b,n_vox", [("mono", 16, 1024), ("bi_reduced", 24, 20000), ("tri_reduced", 32, 20000),
-                                             ("bi_s0", 24, 3000), ("tri_full", 32, 3000)])
+                                             ("bi_s0", 24, 3000), ("tri_full", 32, 3000),
+                                             # odd numbers of b-values: the last value of a row is refilled together with the first
+                                             # value of the next row (and the last row of the array on its own)
+                                             ("mono", 15, 1025), ("bi_reduced", 23, 6001), ("tri_reduced", 31, 6001)])
 @pytest.mark.parametrize("jac", ["fd", "analytic"])
 def test_matches_oracle_seeded(gpu, oracle, model, n_b, n_vox, jac):
     from pyneapple_amd import synth
@@ -352,7 +355,7 @@ def test_host_pipeline_chunking_is_invisible(gpu, monkeypatch):
 def test_streamed_host_path_equals_ring_and_resident(gpu, monkeypatch, capfd, model, n_b, dtype, pcov):
     """Host arrays with shared p0 / bounds run as ONE persistent kernel that waits at an upload watermark and hands finished
     granules to the download while it is still fitting (pnx_api.hip curvefit_streamed).  Ragged granules, upload pieces that
-    do not line up with granules, odd n_b (no LDS-DMA refill) and the float32 entry point must all return, bit for bit,
+    do not line up with granules, odd n_b (the last value of a row is refilled with the next row's first) and the float32 entry point must all return, bit for bit,
     what the chunk ring returns; the fp64 case also equals the device-resident call."""
     import torch
 
