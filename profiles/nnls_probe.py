@@ -12,9 +12,10 @@ from pyneapple_amd import api, synth
 from oracle import pnx_oracle as O
 n = int(%d)
 dev = torch.device("cuda", 0)
-bins, basis, reg = synth.nnls_matrices(32)
+nb_ = int(%d)
+bins, basis, reg = synth.nnls_matrices(nb_)
 plan = api.NnlsPlan(basis, reg, 0)
-_, y = synth.make_torch_rows("tri_reduced", 0, n, 32, dev, sigma=0.01, scale=1000.0)
+_, y = synth.make_torch_rows("tri_reduced", 0, n, nb_, dev, sigma=0.01, scale=1000.0)
 coeff = torch.empty((n, 250), dtype=torch.float64, device=dev); rn = torch.empty(n, dtype=torch.float64, device=dev)
 st = torch.empty(n, dtype=torch.int8, device=dev); it = torch.empty(n, dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
@@ -36,5 +37,5 @@ for lib in libs:
     env = dict(os.environ)
     if lib:
         env["PNX_LIB"] = os.path.abspath(lib)
-    r = subprocess.run([sys.executable, "-c", CHILD % (HERE, n)], env=env, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD % (HERE, n, int(os.environ.get("PNX_PROBE_NB", 32)))], env=env, capture_output=True, text=True)
     print(os.path.basename(lib) or "product", r.stdout.strip() or r.stderr[-1500:], flush=True)

@@ -411,8 +411,9 @@ __device__ __forceinline__ double bx_gather(const double *Bl, const double *xbuf
     return swap_add32((a0 + a1) + (a2 + a3));
 }
 // out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m] as bt_times; `between` runs behind the first eight row reads
+// rows >= n_meas of the LDS basis are zero: the product stops at `mrows` = n_meas rounded up to the eight rows of a loop step
 template <class F>
-__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int lane, double (&out)[kSlots], F &&between) {
+__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int mrows, int lane, double (&out)[kSlots], F &&between) {
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) out[s] = 0;
     const double *col = Bl + 2 * lane;
@@ -424,7 +425,7 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
     }
     between();
 #pragma unroll 1
-    for (int m = 0; m < kBMeas; m += 8) {
+    for (int m = 0; m < mrows; m += 8) {
         const double *nx = col + (m + 4) * kBStride;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -466,7 +467,7 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
 // w = B^T (y - B_P x_P) - R^T (R x), all out of LDS.  LDS round trips in sequence: bins of the first positions -> column
 // gathers (one per 16 positions) -> B^T r; the stencil of R rides on the first gathers, the one of R^T on the first row reads.
 __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbuf, lds_int *ps, double *rb, const double (&rc)[5], int hb,
-                                                   int n, int lane, double yreg, const VoxState &S, double (&w)[kSlots]) {
+                                                   int n, int mrows, int lane, double yreg, const VoxState &S, double (&w)[kSlots]) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     lds_order();
     stage_bins(xbuf, ps, p, lane, S.x, S.pidx);
@@ -487,7 +488,7 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
     const Win ul = load_win(lo), uh = load_win(hi);
     lds_order();
     double u[kSlots];
-    bt_times_h(Bl, rb, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); });  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    bt_times_h(Bl, rb, mrows, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); });  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
     lds_order();
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) {
@@ -861,7 +862,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
                 const int ld = fresh(lane);
                 KArgs *K = kargs();
                 const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
-                dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, ld, yreg, S, w);
+#ifdef PNX_BLK_FULL_ROWS  // (A/B builds) all 32 rows of the LDS basis whatever the plan's number of measurements, as up to round 4
+                const int mrows = kBMeas;
+#else
+                const int mrows = (K->n_meas + 7) & ~7;
+#endif
+                dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, mrows, ld, yreg, S, w);
             }
             STAMP(1);
 
