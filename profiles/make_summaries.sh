@@ -20,7 +20,7 @@ for r in rows[1:]:
 PY
 python3 profiles/traffic_summary.py $src/traffic > profiles/${tag}_traffic.json
 (echo "# curvefit_kernel<4,5,true,false,false,false> (MODEL, N, FD, PV, T1, STREAM), full C3 volume, 1 timed + 1 warm-up launch (profiles/pmc_curvefit.sh)"; python3 profiles/pmc_summary.py $src/pmc_cf curvefit_kernel) > profiles/${tag}_pmc_curvefit.txt
-(echo "# nnls_blk_kernel (pnx_nnls_blk.hip), full C4 volume (one launch of 4 194 304 voxels per step since r04_q; four launches of 2^20 before), profiles/pmc_nnls.sh"; python3 profiles/pmc_summary.py $src/pmc_nnls "nnls_blk_kernel") > profiles/${tag}_pmc_nnls.txt
+(echo "# nnls_blk_kernel (pnx_nnls_blk.hip), full C4 volume = TWO dispatches per step since r04_r (the pilot of 12 288 voxels and the launch over the other 4 182 016: per-dispatch figures are the mean of the two, i.e. per 2 097 152 voxels; four launches of 2^20 before), profiles/pmc_nnls.sh"; python3 profiles/pmc_summary.py $src/pmc_nnls "nnls_blk_kernel") > profiles/${tag}_pmc_nnls.txt
 (echo "# nnls_aty_mfma_kernel (profiles/pmc_traffic.sh, mfma pass)"; python3 profiles/pmc_summary.py $src/traffic/mfma nnls_aty) > profiles/${tag}_pmc_mfma_aty.txt
 cp $src/bench.json profiles/${tag}_bench.json
 python3 - "$tag" <<'PY'
@@ -33,7 +33,7 @@ def parse(fn):
         if m: d[m.group(1)] = float(m.group(4))
     return d
 out = {}
-for name, fn, nvox in (("curvefit_kernel<4, 5, true, false, false, false>", f"profiles/{tag}_pmc_curvefit.txt", 4194304), ("nnls_blk_kernel", f"profiles/{tag}_pmc_nnls.txt", 4194304)):
+for name, fn, nvox in (("curvefit_kernel<4, 5, true, false, false, false>", f"profiles/{tag}_pmc_curvefit.txt", 4194304), ("nnls_blk_kernel", f"profiles/{tag}_pmc_nnls.txt", 4194304 // 2)):
     d = parse(fn)
     f64 = d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_ADD_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d.get("SQ_INSTS_VALU_TRANS_F64", 0)
     fl = 64 * (f64 + d["SQ_INSTS_VALU_FMA_F64"])
@@ -51,7 +51,7 @@ out["_source_ids"] = ids
 json.dump(out, open(f"profiles/{tag}_flops.json", "w"), indent=1)
 t = json.load(open(f"profiles/{tag}_traffic.json"))
 t["_source_ids"] = ids
-t["_nnls_launch_voxels"] = 4194304
+t["_nnls_launch_voxels"] = 4194304 // 2
 json.dump(t, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 for k, v in out.items():
     if isinstance(v, dict) and not k.startswith("_"):
