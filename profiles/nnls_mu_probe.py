@@ -16,7 +16,8 @@ cfg = dict(synth.NNLS_CFG) if hasattr(synth, "NNLS_CFG") else {"d_range": (0.000
 cfg.update(reg_order=order, mu=mu)
 bins, basis, reg = synth.nnls_matrices(32, cfg)
 plan = api.NnlsPlan(basis, reg, 0)
-_, y = synth.make_torch_rows("tri_reduced", 0, n, 32, dev, sigma=0.01, scale=1000.0)
+import os
+_, y = synth.make_torch_rows("tri_reduced", 0, n, 32, dev, sigma=float(os.environ.get("PNX_PROBE_SIGMA", "0.01")), scale=1000.0)
 coeff = torch.empty((n, 250), dtype=torch.float64, device=dev); rn = torch.empty(n, dtype=torch.float64, device=dev)
 st = torch.empty(n, dtype=torch.int8, device=dev); it = torch.empty(n, dtype=torch.int32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
