@@ -147,3 +147,29 @@ def test_bench_two_ranks_as_child_processes_on_one_card():
     head = lines[0][:1500]
     for k in ("nnls_voxels_per_s", "nnls_ms_per_step", "c3_host_voxels_per_s", "c4_host_voxels_per_s", "throughput_voxels_per_s"):
         assert f'"{k}": ' in head
+
+
+def test_bench_two_ranks_under_torch_distributed_run_on_one_card():
+    """The driver's own N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with two ranks on this box's one card (PNX_BENCH_SHARE_GPU, gloo for the barrier
+    and the max-reduce): RANK / LOCAL_RANK / WORLD_SIZE come from the launcher's environment instead of bench.py's own
+    spawner, and rank 0 alone prints the line."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PNX_BENCH_SHARE_GPU="1", PNX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--voxels", "262144", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-host-mode"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["voxels_per_rank"] == [131072, 131072]
+    assert d["value"] > 0 and d["nnls_voxels_per_s"] > 0 and d["check"]["converged_frac"] > 0.995
+    assert len(d["affinity"]) == 2
