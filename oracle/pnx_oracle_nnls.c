@@ -110,8 +110,8 @@ static void tri_solve(const double *A, int m, const int *inds, int nsetp, double
 /* Test hook shared with the HIP block kernel (pnx_nnls_blk.hip, PNX_NNLS_TEST_REJECT=k,n): with nsetp % k == k - 1 the first n
  * candidates of an outer iteration are rejected unseen, so that the kernel's bookkeeping of rejected columns -- which the
  * reference workload never exercises -- can be checked against this restatement.  The kernel's list holds eight columns; a
- * ninth rejection hands the voxel to its general kernel, which knows no hook: mode -2 asks the caller to solve the voxel again
- * without it. */
+ * ninth rejection hands the voxel to the kernel's hand-over target (since the last part of round 4 its four-slot instantiation,
+ * before that the Gram-form kernel), which is run without the hook: mode -2 asks the caller to solve the voxel again without it. */
 static int g_rej_k = 0, g_rej_n = 0;
 #define PNX_ORACLE_MAX_REJ 8
 

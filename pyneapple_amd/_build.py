@@ -29,7 +29,7 @@ NNLS_FLAGS = os.environ.get("PNX_NNLS_FLAGS", "").split()  # e.g. -DPNX_NNLS_GBA
 # measured on, and bench.py only replays counters whose stamp matches the sources it is running
 SOURCE_GROUPS = {
     "curvefit": ["pnx_curvefit_kernel.hpp", "pnx_curvefit_inst.hip"],
-    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp", "pnx_nnls_dev.hpp", "pnx_nnls_qr.hip", "pnx_nnls_blk.hip"],
+    "nnls": ["pnx_nnls.hip", "pnx_nnls.hpp", "pnx_nnls_dev.hpp", "pnx_nnls_qr.hip", "pnx_nnls_blk.hip", "pnx_nnls_blk_kernel.hpp"],
     "sweep": ["pnx_sweep.hip"],
     # the host boundary (streamed path, chunk ring, deferred NNLS hand-over, peak tables): host-mode / PCIe-inclusive figures and
     # the host-path fuzz summaries are stamped with this id, so that they are not replayed as current after pnx_api.hip changes

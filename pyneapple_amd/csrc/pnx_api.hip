@@ -1124,7 +1124,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
                     // stream of its own behind this chunk's solve, while the chunk's spectra go home (8 ms of download, 9 ms of pass)
                     PNX_HIP(hipEventRecord(side.e, s));
                     PNX_HIP(hipStreamWaitEvent(side.s, side.e, 0));
-                    r = nnls_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+                    r = nnls_blk_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
                 }
             } else {
                 r = nnls_solve_device(&P, (int64_t)c, S.y, max_iter, S.c, S.r, S.s, S.i, s);
@@ -1156,7 +1156,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         int r = run_pipeline(n_chunks, n_slots, 1, hg.touchers(), P.device, st, ops);
         if (r || !defer) return r;
         if (!overlap_pass) {  // PNX_NNLS_DEFER_OVERLAP=0: the pass after the ring has drained (round 3's order)
-            int rr = nnls_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+            int rr = nnls_blk_redo_device(&P, defer_cap, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
             if (rr) return rr;
         }
         PNX_HIP(hipStreamSynchronize(side.s));  // the deferred pass (launched behind the last chunk's solve)
@@ -1187,7 +1187,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
                 }
                 PNX_HIP(hipMemcpy(dctx.y_side, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
                 // the list is 0 .. nb - 1 (d_iota) and the count on the device is n >= nb: the kernel stops at the nb it is given
-                int rr = nnls_redo_device(&P, nb, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
+                int rr = nnls_blk_redo_device(&P, nb, dctx.y_side, max_iter, d_sc, d_sr, d_ss, d_si, d_iota, dctx.counters, side.s);
                 if (rr) return rr;
                 PNX_HIP(hipStreamSynchronize(side.s));
             }
@@ -1387,7 +1387,7 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
                 }
                 PNX_HIP(hipMemcpy(dctx.y_side, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
             }
-            if ((r = nnls_redo_device(&P, (int64_t)nb, dctx.y_side, max_iter, o.spec, o.r, o.s, o.i, iota, dctx.counters, st))) return r;
+            if ((r = nnls_blk_redo_device(&P, (int64_t)nb, dctx.y_side, max_iter, o.spec, o.r, o.s, o.i, iota, dctx.counters, st))) return r;
             if ((r = analyse(nb, o, st))) return r;
             PNX_HIP(hipStreamSynchronize(st));
             PNX_HIP(hipMemcpy(hr.data(), o.r, nb * 8, hipMemcpyDeviceToHost));

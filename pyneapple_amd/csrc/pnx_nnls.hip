@@ -946,6 +946,8 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->G) (void)hipFree(P->G);
     if (P->Mglob) (void)hipFree(P->Mglob);
     if (P->Mblk) (void)hipFree(P->Mblk);
+    if (P->Mblk4) (void)hipFree(P->Mblk4);
+    if (P->blk4_bail) (void)hipFree(P->blk4_bail);
     if (P->Mwide) (void)hipFree(P->Mwide);
     if (P->qr_slab) (void)hipFree(P->qr_slab);
     if (P->blk_bail) (void)hipFree(P->blk_bail);

@@ -32,6 +32,9 @@ struct NnlsPlanData {
     int qr_slab_groups = 0;
     bool blk = false;         // banded Toeplitz regulariser and <= 32 measurements: LDS-resident basis, block-distributed factor (pnx_nnls_blk.hip)
     double *Mblk = nullptr;   // its per-wave slabs of the inverse Cholesky factor
+    double *Mblk4 = nullptr;  // the same for the four-slot instantiation (256 positions, eight waves per CU: 270 KB per wave)
+    int blk4_groups = 0;
+    int32_t *blk4_bail = nullptr;  // what the four-slot instantiation hands to the Gram-form kernel (a ninth rejected candidate: test hook only)
     double *Mwide = nullptr;  // wide plans: slabs of the hand-over pass nnls_kernel<8, 8> (rows up to 511), one wave per CU
     int wide_waves = 0;
     int blk_groups = 0;       // its persistent workgroups (16 waves each)
@@ -55,6 +58,9 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
 int nnls_routed_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                        int8_t *status_d, int32_t *iters_d, const int32_t *route, hipStream_t stream);
 bool nnls_blk_applicable(const NnlsPlanData *P);
+// block-kernel plans: the voxels list[0 .. min(*count, n_vox)) through the four-slot block kernel (hand-over target of the two-slot one)
+int nnls_blk_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                         int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream);
 int nnls_blk_plan_init(NnlsPlanData *P);
 // Deferred hand-over (host-array calls made of several chunks, pnx_api.hip): the block kernel appends the voxels it hands over
 // to `bail` with their index within the whole call (`base` + index within this chunk), a gather keeps their signal rows in

@@ -47,1174 +47,40 @@
 #include "pnx_nnls.hpp"
 #include "pnx_nnls_dev.hpp"
 
-namespace pnx {
-
-constexpr int kBMeas = 32;                  // measurements the LDS copy of the basis holds
-constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
+// ---- the two instantiations of the kernel body ---------------------------------------------------------------
+// blk2: two position slots (passive sets up to 128 columns), twelve waves per CU at 168 registers -- every voxel of the reference
+// workload but one in 10^4.  blk4 (last part of round 4): four slots (256 positions: every passive set of a 256-bin plan fits),
+// eight waves per CU at 256 registers, (c, s) pairs of a removal for 256 positions in its LDS scratch.  It takes the voxels blk2
+// hands over -- and whole calls when the pilot finds that blk2 would hand over most of them (strong regularisers) -- so that
+// those run on the residual-form dual too (32 rows of B out of LDS per outer iteration) instead of the Gram form's p rows of G.
+#define PNX_BLK_NS blk2
+#define PNX_BLK_KERNEL nnls_blk_kernel
+#define PNX_BLK_PS 2
 #ifndef PNX_BLK_WAVES
-#define PNX_BLK_WAVES 12  // 168 registers per wave, no scratch.  16 waves (128 registers, 24 rows of M in LDS): 128 bytes of scratch and
-                         // 7.2 against 8.2 M voxels/s (round 4; round 3: 62-83 spilled registers, 17 % slower)
+#define PNX_BLK_WAVES 12
 #endif
-constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU
-constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
-constexpr int kPS = 2;                      // register slots of a position-indexed vector: positions < 128
-constexpr int kMaxPos = kPS * kW;           // a voxel whose passive set wants to grow beyond that is handed to pnx_nnls.hip
-constexpr int kXbuf = 2 + kNnlsMaxBins + 2 + 4;
-// per-wave LDS scratch, in doubles: ps[128] (ints): per passive position the LDS byte address of its bin's entry in xbuf |
-// xbuf[264]: x by bin with a halo of two (then t = R x by bin; the (c, s) pairs of a removal; the staging vector of M^T q; its
-// last four doubles: the list of rejected columns) | rb[32]: residual of the measurements.  Every LDS byte not spent here keeps
-// a row of M on the chip
-constexpr int kPadBin = kNnlsMaxBins;  // bin of the padding positions: column 256 of the LDS basis and xbuf[2 + 256] are zero
-constexpr int kScr = kMaxPos / 2 + kXbuf + 32;
 #ifndef PNX_BLK_LDS_ROWS
 #define PNX_BLK_LDS_ROWS 32
 #endif
-constexpr int kLdsM = PNX_BLK_LDS_ROWS;     // rows of M that live in LDS (whole block rows): what every voxel uses all the time
-constexpr int kLdsMDoubles = (kLdsM / 8 + 1) * (32 * (kLdsM / 8));  // moff(kLdsM)
-constexpr int kMSlab = 32 * 16 * 17 + 64;   // doubles of M per wave: moff(128) = 32 I (I + 1) at I = 16, plus the overrun of a 64-lane row read
-typedef int __attribute__((may_alias)) lds_int;
+#include "pnx_nnls_blk_kernel.hpp"
+#undef PNX_BLK_NS
+#undef PNX_BLK_KERNEL
+#undef PNX_BLK_PS
+#undef PNX_BLK_WAVES
+#undef PNX_BLK_LDS_ROWS
+#define PNX_BLK_NS blk4
+#define PNX_BLK_KERNEL nnls_blk4_kernel
+#define PNX_BLK_PS 4
+#define PNX_BLK_WAVES 8
+#define PNX_BLK_LDS_ROWS 32
+#include "pnx_nnls_blk_kernel.hpp"
+#undef PNX_BLK_NS
+#undef PNX_BLK_KERNEL
+#undef PNX_BLK_PS
+#undef PNX_BLK_WAVES
+#undef PNX_BLK_LDS_ROWS
 
-struct BlkArgs {
-    const double *y;
-    double *coeff;
-    double *rnorm;
-    int8_t *status;
-    int32_t *iters;
-    const double *G;   // (n_bins, 256) zero padded
-    const double *Bp;  // (n_meas, 256) zero padded
-    double *Mglob;     // kMSlab doubles per wave, zero initialised (so that every block a sweep touches is finite)
-    int32_t *n_bail;   // number of voxels handed over to the general kernel ...
-    int32_t *bail;     // ... and their indices (within the call: vox_base + index within the chunk)
-    long long vox_base;  // first voxel of this launch within the call
-    unsigned long long *queue;
-    long long n_vox;
-    int n_meas, n_bins, n_reg, max_iter;
-    double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] (mu included)
-    int rhb;       // half bandwidth, 1 or 2
-    int test_rej_k, test_rej_n;  // test hook (PNX_NNLS_TEST_REJECT=k,n): with p % k == k - 1 the first n candidates of an outer iteration are rejected unseen
-    const int32_t *route;  // non-null: the launch only runs while *route == 0 (the pilot of the call kept the block kernel)
-};
-
-// -DPNX_NNLS_BLK_CHECK: every index into the slab of M / a row of G is range checked; the first violation is reported with
-// printf and the access is redirected to element 0 (diagnostic builds only)
-#ifdef PNX_NNLS_BLK_CHECK
-__device__ int g_blk_err = 0;
-__device__ __noinline__ int ck_(int idx, int lim, int code, int aux) {
-    if (idx < 0 || idx >= lim) {
-        if (atomicAdd(&g_blk_err, 1) == 0) printf("BLK_CHECK code=%d idx=%d lim=%d aux=%d block=%d thread=%d\n", code, idx, lim, aux, (int)blockIdx.x, (int)threadIdx.x);
-        return 0;
-    }
-    return idx;
-}
-#define CK(idx, lim, code, aux) ck_((idx), (lim), (code), (aux))
-#else
-#define CK(idx, lim, code, aux) (idx)
-#endif
-
-// Row i of M starts at moff(i): rows are padded to a multiple of 8 entries, so block row I (rows 8 I .. 8 I + 7) has
-// I + 1 blocks of 8 x 8 and each lane row of a block is one 64-byte line.
-__host__ __device__ constexpr int moff(int i) {
-    const int I = i >> 3, a = i & 7;
-    return (I + 1) * (32 * I + 8 * a);
-}
-
-static_assert(kMSlab >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
-static_assert(kLdsMDoubles == moff(kLdsM) && kLdsM % 8 == 0, "LDS part of M: whole block rows");
-
-// M of one wave: rows < kLdsM in LDS, the others in the wave's global slab (same offsets moff(i) + k in both).  A row index
-// that is wave uniform picks its memory with a scalar branch.
-typedef __attribute__((address_space(3))) double lds_double;
-typedef __attribute__((address_space(1))) double glb_double;
-struct MRef {
-    // typed by address space: a branch "LDS or slab" then cannot be folded into one flat access through a selected base
-    // pointer (a flat access waits for both the LDS and the vector-memory counter)
-    lds_double *l;  // LDS, kLdsMDoubles
-    glb_double *g;  // global slab, kMSlab
-    // The empty asm keeps the two branches apart: without it the compiler folds them into ONE flat access through a selected
-    // base pointer, and a flat access waits for both the LDS and the vector-memory counter.
-    __device__ __forceinline__ double ld(int row, int idx) const {
-        double v;
-        if (row < kLdsM) {
-            asm volatile("" ::: "memory");
-            v = l[idx];
-        } else
-            v = g[CK(idx, kMSlab, 20, row)];
-        return v;
-    }
-    __device__ __forceinline__ void st(int row, int idx, double v) const {
-        if (row < kLdsM) {
-            asm volatile("" ::: "memory");
-            l[idx] = v;
-        } else
-            g[CK(idx, kMSlab, 21, row)] = v;
-    }
-};
-
-// ---- reductions over one axis of the 8 x 8 lane grid (every lane of the group gets the sum) ----------------
-// a DPP lane permutation (every lane has a source): no `old` operand, so no register copy in front of the move
-template <int CTRL> __device__ __forceinline__ double dppx(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double swap_add16(double v) {  // + the lane 16 away (rows of 16 lanes swapped pairwise)
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-__device__ __forceinline__ double swap_add32(double v) {  // + the lane 32 away
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-// a value every lane holds, moved to scalar registers: the branches that depend on it become scalar branches (a per-lane
-// condition around DPP / readlane / permlane code makes the compiler mask a loop that no lane ever leaves alone)
-__device__ __forceinline__ double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-// v_max_f64 as it is: fmax() puts a canonicalising v_max_f64 x, x, x in front of every operand (IEEE mode), three
-// instructions where one does -- the dual values are ordinary numbers or -inf, never signalling NaNs
-__device__ __forceinline__ double max1(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// maximum over the wave, in every lane
-__device__ __forceinline__ double allreduce_max(double v) {
-    v = max1(v, dppx<0xB1>(v));
-    v = max1(v, dppx<0x4E>(v));
-    v = max1(v, dppx<0x141>(v));
-    v = max1(v, dppx<0x128>(v));
-    {
-        const int lo = __double2loint(v), hi = __double2hiint(v);
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = max1(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
-    }
-    {
-        const int lo = __double2loint(v), hi = __double2hiint(v);
-        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = max1(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
-    }
-    return v;
-}
-// over b = lane & 7: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
-__device__ __forceinline__ double allreduce_b(double v) {
-    v += dppx<0xB1>(v);
-    v += dppx<0x4E>(v);
-    v += dppx<0x141>(v);
-    return v;
-}
-// over a = lane >> 3: row_ror 8, then the two swaps
-__device__ __forceinline__ double allreduce_a(double v) {
-    v += dppx<0x128>(v);
-    v = swap_add16(v);
-    v = swap_add32(v);
-    return v;
-}
-
-// Reduce-scatter over a: v[K] is lane (a, b)'s partial sum of column block K; returned is, in the lanes of lane row a, the
-// total of block K = a -- which is position order (position 8 a + b lives in lane 8 a + b).  A swap of two registers
-// moves two blocks per step where an all-reduce would move one: 25 instructions for eight blocks instead of 15 per block.
-__device__ __forceinline__ double rs32(double x, double y) {  // lanes < 32: x + x(lane + 32); lanes >= 32: y + y(lane - 32)
-    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-__device__ __forceinline__ double rs16(double x, double y) {  // even rows of 16 lanes: x + x(next row); odd rows: y + y(previous row)
-    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-template <int NI> __device__ __forceinline__ double reduce_scatter_a(const double (&v)[NI], int la) {
-    static_assert(NI <= 8, "eight lane rows");
-    double R[4], Q[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) R[j] = j < NI ? rs32(v[j], j + 4 < NI ? v[j + 4 < NI ? j + 4 : 0] : 0.0) : 0.0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) Q[j] = rs16(R[j], R[j + 2]);
-    const bool odd = la & 1;
-    const double keep = odd ? Q[1] : Q[0], send = odd ? Q[0] : Q[1];
-    return keep + dppx<0x128>(send);
-}
-
-// lanes <= k as a wave mask in scalar registers (k wave uniform): row masks cost no VALU compare
-__device__ __forceinline__ unsigned long long lanes_le(int k) {
-    return k >= 63 ? ~0ull : (k < 0 ? 0ull : ((2ull << k) - 1ull));
-}
-// position i receives the value of position i + 1, on DPP (wave_shl:1: lane l reads lane l + 1; lane 63 keeps `old` = lane 0 of
-// the next slot): two v_mov_dpp per double instead of two ds_bpermute round trips
-__device__ __forceinline__ double wshl1(double v, double last) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(last), __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(last), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int NS> __device__ __forceinline__ void shift_down_dpp(const double (&a)[NS], double (&out)[NS]) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) out[s] = wshl1(a[s], s + 1 < NS ? rl(a[s + 1 < NS ? s + 1 : s], 0) : 0.0);
-}
-template <int NS> __device__ __forceinline__ void shift_down_dpp_i(const int (&a)[NS], int (&out)[NS]) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-        out[s] = __builtin_amdgcn_update_dpp(s + 1 < NS ? __builtin_amdgcn_readlane(a[s + 1 < NS ? s + 1 : s], 0) : 0, a[s], 0x130, 0xf, 0xf, false);
-}
-
-// ---- products with the LDS-resident basis ------------------------------------------------------------------
-#ifdef PNX_NNLS_STAMP
-__device__ unsigned long long g_blk_rejects = 0;  // rejected candidate columns since the library was loaded (diagnostic builds)
-#define STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
-#define COUNT(k, v) do { cnt[k] += (v); } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#define COUNT(k, v) do {} while (0)
-#endif
-
-// The queue pull sits in a function of its own: inlined, its one-lane branch is merged by the compiler into the control flow
-// of the voxel loop, which then runs under EXEC masks it derives per lane -- around DPP / readlane / permlane code.
-__device__ __noinline__ unsigned long long next_voxel(unsigned long long *queue, int lane) {
-    unsigned long long vq = 0;
-    if (lane == 0) vq = atomicAdd(queue, 1ULL);
-    return vq;
-}
-
-// A copy of the lane id the optimiser cannot see through: what a phase derives from it (LDS addresses, block offsets, lane
-// masks) is computed where the phase starts instead of once per kernel -- hoisted out of the voxel loop those ~40 values
-// do not fit into 128 registers and come back from scratch memory in every inner loop.
-__device__ __forceinline__ int fresh(int lane) {
-    asm volatile("" : "+v"(lane));
-    return lane;
-}
-
-// The kernel arguments are read from the kernarg segment where they are needed (scalar loads), through a pointer the
-// optimiser cannot see through: kept in scalar registers for the whole kernel, the 9 pointers and 5 regulariser
-// coefficients push ~100 SGPRs into VGPR lanes, and every use costs a v_readlane -- a VALU instruction in a VALU-bound kernel.
-typedef const BlkArgs __attribute__((address_space(4))) KArgs;
-__device__ __forceinline__ KArgs *kargs() {
-    KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// owner of a bin: binof(lane, slot) = 128 (slot >> 1) + 2 lane + (slot & 1)
-__device__ __forceinline__ int slot_of_bin(int j) { return ((j >> 7) << 1) | (j & 1); }
-__device__ __forceinline__ int lane_of_bin(int j) { return (j >> 1) & 63; }
-// per-voxel state that the phases below share
-struct VoxState {
-    double q[kPS], x[kPS], z[kPS];  // by position
-    int pidx[kPS];                  // bin of a position
-    unsigned long long inP[kSlots];  // by bin, as wave masks in scalar registers (bit l of inP[s]: bin binof(l, s)); bins >= n_bins count as taken
-    int nrej;                        // columns rejected in this outer iteration (their inP bits are set meanwhile; the bins wait in LDS)
-    int p;
-};
-
-// ---- round 4: the dual with its LDS round trips overlapped ---------------------------------------------------
-typedef __attribute__((address_space(3))) const double lds_cdouble;
-__device__ __forceinline__ unsigned lds_addr(const double *q) { return (unsigned)(size_t)q; }  // the LDS byte address is the low half of the flat one
-__device__ __forceinline__ double lds_at(unsigned a) { return *reinterpret_cast<lds_cdouble *>((size_t)a); }
-// x by bin into xbuf (halo zeroed) and the bins by position into ps, padded with kPadBin to the end of the slot
-__device__ __forceinline__ void stage_bins(double *xbuf, lds_int *ps, int p, int lane, const double (&x)[kPS], const int (&pidx)[kPS]) {
-    const double2 zero2 = {0.0, 0.0};
-    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
-    *reinterpret_cast<double2 *>(lo) = zero2;
-    *reinterpret_cast<double2 *>(hi) = zero2;
-    if (lane < 2) *reinterpret_cast<double2 *>(xbuf + 258 * lane) = zero2;
-    lds_order();
-#pragma unroll
-    for (int s = 0; s < kPS; ++s) {
-        const int i = lane + kW * s;
-        if (kW * s <= p && i < kMaxPos) {  // wave uniform
-            ps[i] = (int)lds_addr(xbuf + 2) + 8 * (i < p ? pidx[s] : kPadBin);  // LDS address of x by bin: a gather of x needs no address arithmetic
-            if (i < p) xbuf[2 + pidx[s]] = x[s];
-        }
-    }
-    lds_order();
-}
-// the pair of bins at q and its two neighbours on either side: three 16-byte reads
-struct Win {
-    double2 lo, mid, hi;
-};
-__device__ __forceinline__ Win load_win(const double *q) {
-    Win w;
-    w.lo = *reinterpret_cast<const double2 *>(q - 2);
-    w.mid = *reinterpret_cast<const double2 *>(q);
-    w.hi = *reinterpret_cast<const double2 *>(q + 2);
-    return w;
-}
-// taps d = -2 .. 2 of out_j = sum_d c[d + 2] v[j + d]  (REV: c[2 - d], the transposed band)
-template <bool REV, int HB> __device__ __forceinline__ void band_eval(const Win &w, const double (&c)[5], double &o0, double &o1) {
-    const double cm1 = REV ? c[3] : c[1], cp1 = REV ? c[1] : c[3], cm2 = REV ? c[4] : c[0], cp2 = REV ? c[0] : c[4];
-    double a = cm1 * w.lo.y, b = cm1 * w.mid.x;
-    a = fma(c[2], w.mid.x, a);
-    b = fma(c[2], w.mid.y, b);
-    a = fma(cp1, w.mid.y, a);
-    b = fma(cp1, w.hi.x, b);
-    if (HB > 1) {
-        a = fma(cm2, w.lo.x, a);
-        b = fma(cm2, w.lo.y, b);
-        a = fma(cp2, w.hi.x, a);
-        b = fma(cp2, w.hi.y, b);
-    }
-    o0 = a;
-    o1 = b;
-}
-template <bool REV> __device__ __forceinline__ void band_eval4(int hb, const Win &wl, const Win &wh, const double (&c)[5], double (&o)[kSlots]) {
-    if (hb > 1) {
-        band_eval<REV, 2>(wl, c, o[0], o[1]);
-        band_eval<REV, 2>(wh, c, o[2], o[3]);
-    } else {
-        band_eval<REV, 1>(wl, c, o[0], o[1]);
-        band_eval<REV, 1>(wh, c, o[2], o[3]);
-    }
-}
-// every lane: (B_P x_P)[m], m = lane & 31, with x read by bin out of xbuf.  Half wave h takes the positions 16 k + 8 h ..
-// + 7 of step k (two ds_read_b128 bring their bins); the bins of step k + 1 are requested before the gathers of step k, so
-// a step costs one LDS round trip.  `between` runs while the gathers of the first step are in flight.
-template <class F>
-__device__ __forceinline__ double bx_gather(const double *Bl, const double *xbuf, const lds_int *ps, int p, int lane, F &&between) {
-    const int m = lane & 31, h = lane >> 5;
-    const unsigned cB = lds_addr(Bl + m * kBStride) - lds_addr(xbuf + 2);  // from x of a bin to this lane's element of the bin's column
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    const lds_int *pj = ps + 8 * h;
-    int4v j0 = *reinterpret_cast<const int4v *>(pj), j1 = *reinterpret_cast<const int4v *>(pj + 4);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    double bv[8], xv[8];
-    auto issue = [&](int i) {
-        const unsigned jv[8] = {(unsigned)j0.x, (unsigned)j0.y, (unsigned)j0.z, (unsigned)j0.w, (unsigned)j1.x, (unsigned)j1.y, (unsigned)j1.z, (unsigned)j1.w};
-        j0 = *reinterpret_cast<const int4v *>(pj + i + 16);  // beyond the staged part: stale entries, never used
-        j1 = *reinterpret_cast<const int4v *>(pj + i + 20);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            bv[u] = lds_at(jv[u] + cB);
-            xv[u] = lds_at(jv[u]);
-        }
-    };
-    auto consume = [&]() {
-        a0 = fma(xv[0], bv[0], a0);
-        a1 = fma(xv[1], bv[1], a1);
-        a2 = fma(xv[2], bv[2], a2);
-        a3 = fma(xv[3], bv[3], a3);
-        a0 = fma(xv[4], bv[4], a0);
-        a1 = fma(xv[5], bv[5], a1);
-        a2 = fma(xv[6], bv[6], a2);
-        a3 = fma(xv[7], bv[7], a3);
-    };
-    issue(0);  // p = 0: padding positions only (zeros)
-    between();
-    consume();
-    for (int i = 16; i < p; i += 16) {
-        issue(i);
-        consume();
-    }
-    return swap_add32((a0 + a1) + (a2 + a3));
-}
-// out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m] as bt_times; `between` runs behind the first eight row reads
-// rows >= n_meas of the LDS basis are zero: the product stops at `mrows` = n_meas rounded up to the eight rows of a loop step
-template <class F>
-__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int mrows, int lane, double (&out)[kSlots], F &&between) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) out[s] = 0;
-    const double *col = Bl + 2 * lane;
-    double2 c0[4], c1[4], d0[4], d1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
-        c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
-    }
-    between();
-#pragma unroll 1
-    for (int m = 0; m < mrows; m += 8) {
-        const double *nx = col + (m + 4) * kBStride;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
-            d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
-        }
-        {
-            const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
-            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 2);
-            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[0] = fma(c0[r].x, vv[r], out[0]);
-                out[1] = fma(c0[r].y, vv[r], out[1]);
-                out[2] = fma(c1[r].x, vv[r], out[2]);
-                out[3] = fma(c1[r].y, vv[r], out[3]);
-            }
-        }
-        const double *ny = col + ((m + 8) & (kBMeas - 1)) * kBStride;  // the last step re-reads rows 0 .. 3 (unused)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            c0[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride);
-            c1[r] = *reinterpret_cast<const double2 *>(ny + r * kBStride + 128);
-        }
-        {
-            const double2 v01 = *reinterpret_cast<const double2 *>(v + m + 4);
-            const double2 v23 = *reinterpret_cast<const double2 *>(v + m + 6);
-            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                out[0] = fma(d0[r].x, vv[r], out[0]);
-                out[1] = fma(d0[r].y, vv[r], out[1]);
-                out[2] = fma(d1[r].x, vv[r], out[2]);
-                out[3] = fma(d1[r].y, vv[r], out[3]);
-            }
-        }
-    }
-}
-// w = B^T (y - B_P x_P) - R^T (R x), all out of LDS.  LDS round trips in sequence: bins of the first positions -> column
-// gathers (one per 16 positions) -> B^T r; the stencil of R rides on the first gathers, the one of R^T on the first row reads.
-__device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbuf, lds_int *ps, double *rb, const double (&rc)[5], int hb,
-                                                   int n, int mrows, int lane, double yreg, const VoxState &S, double (&w)[kSlots]) {
-    const int p = __builtin_amdgcn_readfirstlane(S.p);
-    lds_order();
-    stage_bins(xbuf, ps, p, lane, S.x, S.pidx);
-    double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
-    const Win wl = load_win(lo), wh = load_win(hi);
-    double t[kSlots];
-    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() { band_eval4<false>(hb, wl, wh, rc, t); });
-    lds_order();
-    if (lane < kBMeas) rb[lane] = yreg - bx;
-    // t by bin through xbuf: every gather of x has been issued, and the LDS executes a wave's instructions in order
-    *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
-    *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
-    lds_order();
-    // rows >= n of R do not exist: x is zero there, so only t_n and t_{n + 1} can be non-zero -- two stores instead of a
-    // select on every lane's four values
-    if (lane < 2) xbuf[2 + n + lane] = 0.0;
-    lds_order();
-    const Win ul = load_win(lo), uh = load_win(hi);
-    lds_order();
-    double u[kSlots];
-    bt_times_h(Bl, rb, mrows, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); });  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
-    lds_order();
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
-        w[s] -= u[s];
-        if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s])) w[s] = -INFINITY;
-    }
-}
-
-// blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
-// The block rows of M that live in the global slab (8 I >= kLdsM), K <= I < NI: every load is issued before the first use.
-template <int NI> __device__ __forceinline__ void load_blocks(const MRef &M, int la, int lb, double (&blk)[NI][NI]) {
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {
-        if (8 * I < kLdsM) continue;
-        const int base = (I + 1) * (32 * I + 8 * la) + lb;
-#pragma unroll
-        for (int K = 0; K <= I; ++K) blk[I][K] = M.g[CK(base + 8 * K, kMSlab, 1, I)];
-    }
-}
-// Block row I of M: out of LDS when it is needed (short latency, no register held meanwhile), else the preloaded copy.
-template <int NI> __device__ __forceinline__ void block_row(const MRef &M, int I, int la, int lb, const double (&blk)[NI][NI],
-                                                            double (&row)[NI]) {
-    const int base = (I + 1) * (32 * I + 8 * la) + lb;
-#pragma unroll
-    for (int K = 0; K < NI; ++K)
-        if (K <= I) row[K] = 8 * I < kLdsM ? M.l[base + 8 * K] : blk[I][K];
-}
-
-// Column jmax wants to enter.  l = M g (g = G[P, jmax]), lam^2 = G_jj - |l|^2, Lawson-Hanson independence test; when it
-// passes: new row of M = [-(l^T M) / lam, 1 / lam], z = x + row * qn (x == M^T q whenever a column enters), q_p = qn.
-// Returns false when the column is rejected (nothing changed).
-// One sweep over the blocks: block row I gives l_{8 I + a} (FMA per block, butterfly over b), which goes straight into
-// the column sums of l^T M, so a block is dead once its row is done; all block loads are issued up front.
-// What an append needs that does not depend on the candidate, requested before the arg-max so that its latency hides behind it:
-// the bins of the positions in column layout (as byte offsets into a row of G).  (The blocks of M that live in the slab would
-// qualify too, but held across the arg-max they push the append out of its registers: 64 -> 256 bytes of scratch, measured.)
-template <int NI>
-__device__ __forceinline__ void append_prefetch(const lds_int *ps, int lb, unsigned (&goff)[NI]) {
-    const int ps_base = (int)lds_addr(reinterpret_cast<const double *>(ps) + kMaxPos / 2 + 2);  // = xbuf + 2 of this wave
-#pragma unroll
-    for (int K = 0; K < NI; ++K) goff[K] = (unsigned)(ps[8 * K + lb] - ps_base);  // ps holds LDS addresses of x by bin
-}
-template <int NI>
-__device__ __forceinline__ bool try_append(const double *G, const MRef &M, const lds_int *ps, int lane, int la, int lb, int jmax,
-                                           double wj, VoxState &S
-                                           , const unsigned (&goff)[NI]
-) {
-    const int p = __builtin_amdgcn_readfirstlane(S.p);
-    const double *grow = G + (size_t)jmax * kNnlsMaxBins;
-    double blk[NI][NI];
-    wave_sync();  // this wave's stores to M (previous append / removal) have long landed: the wait is free, the order is kept
-    load_blocks<NI>(M, la, lb, blk);
-    const double Gjj = uni(grow[CK(jmax, kNnlsMaxBins, 2, p)]);
-    // g in column layout: lane (a, b) holds g_{8 K + b}
-    double gc[NI];
-#pragma unroll
-    for (int K = 0; K < NI; ++K) {  // no mask: behind position p the staged bins are 0 and the columns of M are zero
-        gc[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + goff[K]);
-    }
-    double rK[NI];  // column sums of l^T M, lane (a, b) holds the partial sum over its rows of column 8 K + b
-#pragma unroll
-    for (int K = 0; K < NI; ++K) rK[K] = 0;
-    double ll = 0;
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {
-        double acc = 0, row[NI];
-        block_row<NI>(M, I, la, lb, blk, row);
-#pragma unroll
-        for (int K = 0; K <= I; ++K) acc = fma(row[K], gc[K], acc);
-        double lr = allreduce_b(acc);  // l_{8 I + a}, the same in the lanes (a, *)
-        // rows >= p: zero in the LDS part of M (kept so: no mask); in the global part they may hold a previous voxel's values
-        if (8 * I >= kLdsM) lr = (8 * I + la < p) ? lr : 0.0;
-        ll = fma(lr, lr, ll);
-#pragma unroll
-        for (int K = 0; K <= I; ++K) rK[K] = fma(row[K], lr, rK[K]);
-    }
-    ll = allreduce_a(ll);
-    // rows >= 48: row by row (lanes over the columns), four rows in flight
-    double a1[kPS] = {0, 0};    // l^T M by position
-    if (NI == 6 && p > kRows2D) {
-        double g[kPS];
-#pragma unroll
-        for (int s = 0; s < kPS; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
-        auto one = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            const int rbase = moff(i);
-            double part = 0, m[si + 1];
-#pragma unroll
-            for (int s = 0; s <= si; ++s) {
-                const int k = lane + kW * s;
-                m[s] = (k <= i) ? M.g[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end: masked
-                part = fma(m[s], g[s], part);
-            }
-            const double li = wave_sum(part);
-            ll = fma(li, li, ll);
-#pragma unroll
-            for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[s], a1[s]);
-        };
-        auto four = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            double m[4][si + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rbase = moff(i + r);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
-            }
-            double part[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                part[r] = 0;
-#pragma unroll
-                for (int s = 0; s <= si; ++s) {
-                    m[r][s] = (lane + kW * s <= i + r) ? m[r][s] : 0.0;
-                    part[r] = fma(m[r][s], g[s], part[r]);
-                }
-            }
-            // the four wave sums in one go: two 32-lane swaps fold rows (0, 2) and (1, 3) into half waves, a 16-lane swap folds
-            // those into quarter waves (row r in lanes 16 r .. 16 r + 15), four butterfly steps finish all four at once --
-            // 29 instructions for the four totals instead of 20 per row
-            double t = rs16(rs32(part[0], part[2]), rs32(part[1], part[3]));
-            t += dppx<0xB1>(t);   // quad_perm [1,0,3,2]
-            t += dppx<0x4E>(t);   // quad_perm [2,3,0,1]
-            t += dppx<0x141>(t);  // row_half_mirror
-            t += dppx<0x140>(t);  // row_mirror
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double li = rl(t, 16 * r);
-                ll = fma(li, li, ll);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[r][s], a1[s]);
-            }
-        };
-        for_pos4n<kPS>(kRows2D, p, four, one);
-    }
-    ll = uni(ll);
-    // wave-uniform scalar algebra on v_rsq_f64 + Newton (pnx_nnls.hip)
-    const double lam2 = Gjj - ll;
-    const bool indep = lam2 > 64.0 * 2.220446049250313e-16 * Gjj;
-    const double ilam = indep ? rsqrt_nr(lam2) : 0.0;
-    double lam = lam2 * ilam;
-    lam = fma(0.5 * ilam, fma(-lam, lam, lam2), lam);  // sqrt(lam2) to within an ulp
-    // Lawson-Hanson linear-independence test: (|l| + 0.01 lam) - |l| > 0.  It can only fail where 0.01 lam is below half an
-    // ulp of |l|, i.e. lam^2 < ~1e-28 |l|^2: |l| = sqrt(ll) is computed on that side of a generous threshold only
-    bool ok = true;
-    if (!(lam2 > 1e-24 * ll)) {
-        const double un = ll > 0 ? ll * rsqrt_nr(ll) : 0.0;
-        ok = ((un + lam * 0.01) - un) > 0;
-    }
-    // ztest = qn / lam with qn = (a_j^T residual) / lam: the residual-form dual w_j IS a_j^T residual
-    const double qn = wj * ilam;
-    ok = ok && qn > 0;
-    if (!ok) return false;
-#ifdef PNX_NNLS_TRACE
-    if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) printf("A p=%d j=%d lam=%.17g qn=%.17g\n", p, jmax, lam, qn);
-#endif
-    // column sums over a, delivered in position order (position 8 la + lb is column block K = la)
-    a1[0] += reduce_scatter_a<NI>(rK, la);
-    // the new row by position: -(l^T M) / lam in front of position p (beyond it l^T M is zero: those columns of M are), 1 / lam
-    // at p.  The masks are scalar (p is wave uniform): no vector compare, and the second register slot only where it is in use.
-    {
-        const int pbase = moff(p);
-        const int width = 8 * ((p >> 3) + 1);
-        const int sp = p >> 6;
-        const unsigned long long bit = 1ull << (p & 63);
-#pragma unroll
-        for (int s = 0; s < kPS; ++s) {
-            if (s == 0 || p >= kW) {  // wave uniform
-                const unsigned long long at_p = s == sp ? bit : 0ull;
-                double rowv = -a1[s] * ilam;
-                if (__builtin_amdgcn_inverse_ballot_w64(at_p)) {
-                    rowv = ilam;
-                    S.x[s] = 0.0;
-                    S.q[s] = qn;
-                    S.pidx[s] = jmax;
-                }
-                if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
-                S.z[s] = fma(rowv, qn, S.x[s]);  // the rank-one update of the solution: z = x + row * qn (x_p = 0)
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s)
-        S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;  // scalar: jmax is wave uniform
-    S.p = p + 1;
-    return true;
-}
-
-constexpr int kMaxRej = 8;  // rejected columns an outer iteration can remember (the four spare doubles behind xbuf's halo)
-// The candidate step of an outer iteration: largest positive dual (ties: lowest bin), then the append.  Returns 0 when no dual
-// is positive (KKT satisfied), 1 when the column entered, 2 when it was rejected, 3 when it was rejected and the list is full.
-// A rejected column is what Lawson-Hanson answers with "w_j = 0, take the next largest".  It is rare (none in 28 000 outer
-// iterations of the reference workload), so it is not worth a loop around the append -- a loop keeps w[] and a copy of the
-// voxel state alive across the append and lets the compiler hoist the append's addresses in front of it: 64 bytes of scratch
-// per lane written in every outer iteration, which on this chip is HBM traffic.  Instead the column's passive flag is set for
-// the time being, its bin is remembered in LDS, and the outer loop evaluates the dual again (same state, same values; the
-// flag masks the column); the flags are taken back when a column enters.
-template <int NI>
-__device__ __forceinline__ int candidate(const double *G, const MRef &M, const lds_int *ps, lds_int *rejlist, int lc, const double (&w)[kSlots],
-                                         VoxState &S) {
-    const int la = lc >> 3, lb = lc & 7;
-    unsigned goff[NI];
-    append_prefetch<NI>(ps, lb, goff);
-    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-    if (!(best > 0)) return 0;  // KKT satisfied
-    // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
-    int jmax;
-    {
-        const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
-        const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
-        const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
-        const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
-        const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
-        const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
-        const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
-        jmax = lo < hi ? lo : hi;
-    }
-    if (jmax == kNone) return 0;  // cannot happen (some lane holds the maximum); never index G with it
-    // test hook: reject valid columns, so that the bookkeeping of rejected columns runs although the reference workload never
-    // rejects one (the minimiser is unique with a regulariser: the solve must arrive at the same spectrum by another path)
-    const int tk = kargs()->test_rej_k;
-    const bool forced = tk > 0 && (__builtin_amdgcn_readfirstlane(S.p) % tk) == tk - 1 && __builtin_amdgcn_readfirstlane(S.nrej) < kargs()->test_rej_n;
-    if (!forced && try_append<NI>(G, M, ps, lc, la, lb, jmax, best, S, goff)) {
-        const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
-        for (int k = 0; k < nr; ++k) {  // the columns rejected meanwhile may be looked at again
-            const int j = __builtin_amdgcn_readfirstlane(rejlist[k]);
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s) S.inP[s] &= ~((s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull);
-        }
-        S.nrej = 0;
-        return 1;
-    }
-    const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
-    if (nr >= kMaxRej) return 3;
-    if (lc == 0) rejlist[nr] = jmax;
-    S.nrej = nr + 1;
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;
-    return 2;
-}
-
-// z = M^T q
-template <int NI>
-__device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane, int la, int lb, VoxState &S) {
-    const int p = __builtin_amdgcn_readfirstlane(S.p);
-    double blk[NI][NI];
-    wave_sync();
-    load_blocks<NI>(M, la, lb, blk);
-    lds_order();
-    stg[lane] = S.q[0];
-    lds_order();
-    double qr[NI];
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {  // LDS rows >= p of M are zero: what q holds there does not matter; global rows are masked
-        qr[I] = stg[8 * I + la];
-        if (8 * I >= kLdsM) qr[I] = (8 * I + la < p) ? qr[I] : 0.0;
-    }
-    lds_order();
-    double zK[NI];
-#pragma unroll
-    for (int K = 0; K < NI; ++K) zK[K] = 0;
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {
-        double row[NI];
-        block_row<NI>(M, I, la, lb, blk, row);
-#pragma unroll
-        for (int K = 0; K <= I; ++K) zK[K] = fma(row[K], qr[I], zK[K]);
-    }
-    S.z[0] = reduce_scatter_a<NI>(zK, la);
-#pragma unroll
-    for (int s = 1; s < kPS; ++s) S.z[s] = 0;
-    if (NI == 6 && p > kRows2D) {
-        auto one = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            const double a = rl(S.q[si], i & 63);
-            const int rbase = moff(i);
-#pragma unroll
-            for (int s = 0; s <= si; ++s) {
-                const int k = lane + kW * s;
-                const double m0 = M.g[CK(rbase + k, kMSlab, 5, i)];
-                S.z[s] += a * ((k <= i) ? m0 : 0.0);
-            }
-        };
-        auto four = [&](int i, auto T) {
-            constexpr int si = decltype(T)::value;
-            double m[4][si + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rbase = moff(i + r);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double a = rl(S.q[si], (i + r) & 63);
-#pragma unroll
-                for (int s = 0; s <= si; ++s) S.z[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
-            }
-        };
-        for_pos4n<kPS>(kRows2D, p, four, one);
-    }
-}
-
-constexpr int kBail = 2;  // internal status: the passive set wants more than kMaxPos columns, the general kernel redoes the voxel
-
-__global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) {  // read through kargs()
-#ifdef PNX_NNLS_STAMP
-    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-    long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // voxels, outer iterations, rejected candidates, removals, rotated rows, sum of p at the dual, appends with p > 48, p > 64
-#endif
-    extern __shared__ double dyn_lds[];
-    if (kargs()->route && *kargs()->route != 0) return;  // uniform over the grid: the pilot of this call chose the Gram-form kernel
-    const int lane = threadIdx.x & (kW - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = kargs()->n_bins, nm = kargs()->n_meas, nreg = kargs()->n_reg;
-    const int m_total = nm + nreg;
-    // the per-wave scratch comes first: its addresses then fit the 16-bit offset field of the DS instructions (behind the
-    // 66 KB of B every access needed a VALU add for its address: 18 of them per step of the B x loop alone)
-    double *scr = dyn_lds + wave * kScr;
-    double *Bl = dyn_lds + kBlkWaves * kScr;
-    lds_int *ps = reinterpret_cast<lds_int *>(scr);                    // [128] bin by position
-    double *xbuf = scr + kMaxPos / 2;                                  // [kXbuf] x by bin (halo of 2), staging buffer of the M sweeps
-    double *rb = xbuf + kXbuf;                                         // [32] residual of the measurements
-    MRef M;
-    M.g = (glb_double *)(kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab);
-    M.l = (lds_double *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles);
-    for (int e = lane; e < kLdsMDoubles; e += kW) M.l[e] = 0.0;  // rows >= p of M are zero, from the first voxel on
-    for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
-        const int m = e / kBStride, j = e - m * kBStride;
-        Bl[e] = (m < nm && j < kNnlsMaxBins) ? kargs()->Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
-    }
-    __syncthreads();  // the only workgroup barrier: from here on the waves never meet again
-
-    for (;;) {
-        unsigned long long vq = next_voxel(kargs()->queue, lane);
-        vq = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vq >> 32)) << 32) |
-             (unsigned)__builtin_amdgcn_readfirstlane((int)vq);
-        if (vq >= (unsigned long long)kargs()->n_vox) break;
-        const long long vox = (long long)vq;
-        const double *yv = kargs()->y + (size_t)vox * nm;
-
-        // y by measurement: lanes 0 .. 31, duplicated in 32 .. 63
-        const int ml = lane & 31;
-        const double yreg = ml < nm ? yv[ml] : 0.0;
-        const bool finite = __all(isfinite(yreg) ? 1 : 0) != 0;
-        VoxState S;
-#pragma unroll
-        for (int s = 0; s < kPS; ++s) {
-            S.q[s] = 0;
-            S.x[s] = 0;
-            S.z[s] = 0;
-            S.pidx[s] = 0;
-        }
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) S.inP[s] = __ballot(binof(lane, s) >= n);
-        S.p = 0;
-        S.nrej = 0;
-        int iteration = 0, status = finite ? 1 : -2;
-        double w[kSlots];
-        STAMP(0);
-        COUNT(0, 1);
-
-        while (status == 1 && S.p < n && S.p < m_total) {
-            // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
-            COUNT(1, 1);
-            COUNT(5, S.p);
-            COUNT(6, S.p > 48 ? 1 : 0);
-            COUNT(7, S.p > 64 ? 1 : 0);
-            {
-                const int ld = fresh(lane);
-                KArgs *K = kargs();
-                const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
-#ifdef PNX_BLK_FULL_ROWS  // (A/B builds) all 32 rows of the LDS basis whatever the plan's number of measurements, as up to round 4
-                const int mrows = kBMeas;
-#else
-                const int mrows = (K->n_meas + 7) & ~7;
-#endif
-                dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, mrows, ld, yreg, S, w);
-            }
-            STAMP(1);
-
-            bool accepted = false;
-            {
-                if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: hand the voxel over unless it is done
-                    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-                    if (best > 0) status = kBail;
-                } else {
-                    const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
-                    const int lc = fresh(lane);
-                    const double *Gp = kargs()->G;
-                    lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);  // the four spare doubles behind the halo
-                    int r;
-                    if (nI <= 2)
-                        r = candidate<2>(Gp, M, ps, rejlist, lc, w, S);
-                    else if (nI <= 4)
-                        r = candidate<4>(Gp, M, ps, rejlist, lc, w, S);
-                    else
-                        r = candidate<6>(Gp, M, ps, rejlist, lc, w, S);
-                    r = __builtin_amdgcn_readfirstlane(r);
-                    if (r == 2) {
-                        COUNT(2, 1);
-#ifdef PNX_NNLS_STAMP
-                        if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
-#endif
-                        continue;  // a rejected column: its flag is set, the dual is evaluated again
-                    }
-                    if (r == 3) status = kBail;  // more rejections in one outer iteration than the list holds: the general kernel
-                    accepted = r == 1;
-                }
-            }
-            STAMP(2);
-            if (!accepted) break;
-            STAMP(3);
-
-            // ---- inner loop: keep the passive-set solution feasible
-            for (;;) {
-                iteration += 1;
-                if (iteration == kargs()->max_iter) {
-                    status = 0;
-                    break;
-                }
-                const int p = __builtin_amdgcn_readfirstlane(S.p);
-                // positions with z <= 0 as wave masks (the range test i < p is scalar: no vector compare, and the second
-                // register slot is looked at only where it is in use)
-                unsigned long long vm[kPS];
-                vm[0] = __ballot(S.z[0] <= 0) & lanes_le(p - 1);
-                vm[1] = p > kW ? (__ballot(S.z[1] <= 0) & lanes_le(p - 1 - kW)) : 0ull;
-                if (!(vm[0] | vm[1])) {  // feasible: x = z (positions >= p hold nothing that is read)
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s) S.x[s] = S.z[s];
-                    break;
-                }
-                double T[kPS];
-#pragma unroll
-                for (int s = 0; s < kPS; ++s) {
-                    T[s] = INFINITY;
-                    if (vm[s]) {  // wave uniform
-                        if (__builtin_amdgcn_inverse_ballot_w64(vm[s])) T[s] = -S.x[s] / (S.z[s] - S.x[s]);
-                    }
-                }
-                // smallest step (ties: first position -- Lawson-Hanson keeps the first minimum)
-                const double alpha = -uni(allreduce_max(-(T[1] < T[0] ? T[1] : T[0])));
-                int bpos;
-                {
-                    const unsigned long long b0 = __ballot(T[0] == alpha) & vm[0];
-                    const unsigned long long b1 = __ballot(T[1] == alpha) & vm[1];
-                    bpos = b0 ? __ffsll(b0) - 1 : (b1 ? kW + __ffsll(b1) - 1 : kNone);
-                    if (!(alpha < INFINITY)) bpos = kNone;
-                }
-                if (bpos == kNone) {  // no finite step: as Lawson-Hanson, nothing to remove
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s) S.x[s] = S.z[s];
-                    break;
-                }
-#pragma unroll
-                for (int s = 0; s < kPS; ++s) S.x[s] = S.x[s] + alpha * (S.z[s] - S.x[s]);
-                STAMP(4);
-                int jj = bpos;
-                for (;;) {
-                    jj = __builtin_amdgcn_readfirstlane(jj);
-                    const int pp = __builtin_amdgcn_readfirstlane(S.p);
-                    // ---- position jj leaves the passive set: Givens rotations on adjacent rows of M (column jj
-                    // removed) that annihilate m = M[:, jj]; coefficients from the prefix norms of m
-                    // Round 4: the rotation coefficients travel through LDS (one broadcast ds_read_b128 per row instead of
-                    // four v_readlane), q is rotated in closed form (the carried combination of q is a prefix sum:
-                    // carq_i = sum_{k = jj .. i} m_k q_k / a_i), row masks are scalar (no v_cmp), shifts are DPP moves;
-                    // batches of rows that lie wholly in LDS or wholly in the slab carry no per-row branch.
-                    double mv[kPS], pre[kPS], car[kPS];
-                    double carry = 0;
-                    wave_sync();
-                    int cofs[kPS];  // column read of the next row: column jj dropped
-                    {
-                        const int jbase = moff(jj);
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s) {  // column jj (rows jj ..) and row jj (columns < jj): both reads in flight
-                            const int i = lane + kW * s;
-                            mv[s] = (kW * s < pp && i >= jj && i < pp) ? (i < kLdsM ? M.l[i < kLdsM ? moff(i) + jj : 0] : M.g[CK(moff(i) + jj, kMSlab, 9, i)]) : 0.0;
-                            car[s] = (i < jj) ? M.ld(jj, jbase + i) : 0.0;
-                            cofs[s] = i < jj ? i : i + 1;
-                        }
-                    }
-                    double tq[kPS];  // prefix sums of m_k q_k
-                    {
-                        double carry2 = 0;
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s) {
-                            pre[s] = carry;
-                            tq[s] = carry2;
-                            if (kW * s < pp) {
-                                const double sc = wave_incl_scan(mv[s] * mv[s]);
-                                pre[s] = sc + carry;
-                                carry += rl(sc, 63);
-                                const double sq = wave_incl_scan(mv[s] * S.q[s]);
-                                tq[s] = sq + carry2;
-                                carry2 += rl(sq, 63);
-                            }
-                        }
-                    }
-                    double mnext[kPS], prenext[kPS], qsh[kPS];
-                    shift_down_dpp(mv, mnext);
-                    shift_down_dpp(pre, prenext);
-                    shift_down_dpp(S.q, qsh);  // qsh[i] = q[i + 1]
-                    const int bin_out = jj < kW ? __builtin_amdgcn_readlane(S.pidx[0], jj & 63)
-                                                : __builtin_amdgcn_readlane(S.pidx[1], jj & 63);
-                    double2 *cf = reinterpret_cast<double2 *>(xbuf);  // (c_i, s_i) by position: xbuf is free during a removal
-                    lds_order();
-#pragma unroll
-                    for (int s = 0; s < kPS; ++s) {
-                        const int i = lane + kW * s;
-                        if (kW * s < pp) {  // wave uniform
-                            double c_ = 1.0, s_ = 0.0;
-                            if (i >= jj && i < pp - 1) {
-                                // a = sqrt(pre) (the first carried value keeps its sign), r = sqrt(prenext): c = m_next / r, s = a / r
-                                const double ir = prenext[s] > 0 ? rsqrt_nr(prenext[s]) : 0.0;
-                                const double ip = pre[s] > 0 ? rsqrt_nr(pre[s]) : 0.0;
-                                const double a = (i == jj) ? mv[s] : pre[s] * ip;
-                                if (prenext[s] > 0) {
-                                    c_ = mnext[s] * ir;
-                                    s_ = a * ir;
-                                }
-                                const double cq = (i == jj) ? S.q[s] : tq[s] * ip;
-                                S.q[s] = c_ * cq - s_ * qsh[s];
-                            }
-                            cf[i] = double2{c_, s_};
-                        }
-                    }
-                    lds_order();
-                    STAMP(11);
-                    COUNT(3, 1);
-                    COUNT(4, pp - 1 - jj);
-                    {
-                        // row i of the new factor from the carried combination and old row i + 1 (column jj dropped); the
-                        // loads of a batch of rows and their coefficients are in flight before its first rotation
-                        auto rows = [&](int i, auto T, auto NB, auto RG) {
-                            constexpr int si = decltype(T)::value;
-                            constexpr int nb = decltype(NB)::value;
-                            constexpr int rg = decltype(RG)::value;  // 0: rows i .. i + nb in LDS, 1: all in the slab, 2: decided per row
-                            double nx[nb][si + 1];
-                            double2 c2[nb];
-                            int mo[nb + 1];  // moff(i) .. moff(i + nb)
-                            mo[0] = moff(i);
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) mo[r + 1] = moff(i + r + 1);  // (the recurrence moff(k + 1) = moff(k) + 8 (k / 8 + 1) measured 4 % slower: a dependent chain)
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) {
-                                const int nbase = mo[r + 1];
-#pragma unroll
-                                for (int s = 0; s <= si; ++s) {
-                                    const int idx = nbase + cofs[s];
-                                    nx[r][s] = rg == 0 ? M.l[idx] : (rg == 1 ? M.g[CK(idx, kMSlab, 10, i + r)] : M.ld(i + r + 1, idx));
-                                }
-                            }
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) c2[r] = cf[i + r];
-#pragma unroll
-                            for (int r = 0; r < nb; ++r) {
-                                const double c_ = c2[r].x, s_ = c2[r].y;
-                                const int obase = mo[r];
-#pragma unroll
-                                for (int s = 0; s <= si; ++s) {
-                                    if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(i + r - kW * s))) {
-                                        const double outv = c_ * car[s] - s_ * nx[r][s];
-                                        car[s] = s_ * car[s] + c_ * nx[r][s];
-                                        const int oidx = obase + lane + kW * s;
-                                        if (rg == 0)
-                                            M.l[oidx] = outv;
-                                        else if (rg == 1)
-                                            M.g[CK(oidx, kMSlab, 11, i + r)] = outv;
-                                        else
-                                            M.st(i + r, oidx, outv);
-                                    }
-                                }
-                            }
-                        };
-                        const int hi = pp - 1;
-                        const int e = hi < kW ? hi : kW;
-                        int i = jj;
-                        while (i < e) {  // rows < 64: one register slot
-                            const int left = e - i;
-                            if (i >= kLdsM) {
-                                if (left >= 8) {
-                                    rows(i, SlotTag<0>{}, SlotTag<8>{}, SlotTag<1>{});
-                                    i += 8;
-                                } else if (left >= 4) {
-                                    rows(i, SlotTag<0>{}, SlotTag<4>{}, SlotTag<1>{});
-                                    i += 4;
-                                } else {
-                                    rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<1>{});
-                                    i += 1;
-                                }
-                            } else if (left >= 8 && i + 8 < kLdsM) {
-                                rows(i, SlotTag<0>{}, SlotTag<8>{}, SlotTag<0>{});
-                                i += 8;
-                            } else if (left >= 4 && i + 4 < kLdsM) {
-                                rows(i, SlotTag<0>{}, SlotTag<4>{}, SlotTag<0>{});
-                                i += 4;
-                            } else if (i + 1 < kLdsM) {
-                                rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<0>{});
-                                i += 1;
-                            } else {
-                                rows(i, SlotTag<0>{}, SlotTag<1>{}, SlotTag<2>{});
-                                i += 1;
-                            }
-                        }
-                        if (hi > kW) {
-                            i = jj > kW ? jj : kW;
-                            for (; i + 4 <= hi; i += 4) rows(i, SlotTag<1>{}, SlotTag<4>{}, SlotTag<1>{});
-                            for (; i < hi; ++i) rows(i, SlotTag<1>{}, SlotTag<1>{}, SlotTag<1>{});
-                        }
-                    }
-                    // ---- drop position jj from x / pidx
-                    {
-                        double xsh[kPS];
-                        int psh[kPS];
-                        shift_down_dpp(S.x, xsh);
-                        shift_down_dpp_i(S.pidx, psh);
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s) {
-                            const int i = lane + kW * s;
-                            if (i >= jj && i < pp - 1) {
-                                S.x[s] = xsh[s];
-                                S.pidx[s] = psh[s];
-                            }
-                        }
-#pragma unroll
-                        for (int s = 0; s < kSlots; ++s)
-                            S.inP[s] &= ~((s == slot_of_bin(bin_out)) ? (1ull << lane_of_bin(bin_out)) : 0ull);
-                    }
-                    if (pp - 1 < kLdsM) {  // the vacated last row: LDS rows >= p of M stay zero (the block sweeps mask global rows only)
-                        const int vbase = moff(pp - 1);
-                        const int width = 8 * (((pp - 1) >> 3) + 1);
-#pragma unroll
-                        for (int s = 0; s < kPS; ++s)
-                            if (lane + kW * s < width) M.st(pp - 1, vbase + lane + kW * s, 0.0);
-                    }
-                    S.p = pp - 1;
-                    // ---- round-off clean-up: any remaining x <= 0 leaves too (first position first)
-                    int bad;
-                    {
-                        const int pn = pp - 1;
-                        const unsigned long long b0 = __ballot(S.x[0] <= 0) & lanes_le(pn - 1);
-                        const unsigned long long b1 = pn > kW ? (__ballot(S.x[1] <= 0) & lanes_le(pn - 1 - kW)) : 0ull;
-                        bad = b0 ? __ffsll(b0) - 1 : (b1 ? kW + __ffsll(b1) - 1 : kNone);
-                    }
-                    if (bad == kNone) break;
-                    jj = bad;
-                }
-                STAMP(5);
-                // ---- z = M^T q
-                {
-                    const int nI = (S.p + 7) >> 3;
-                    const int lm = fresh(lane);
-                    if (nI <= 2)
-                        mt_times_q<2>(M, xbuf, lm, lm >> 3, lm & 7, S);
-                    else if (nI <= 4)
-                        mt_times_q<4>(M, xbuf, lm, lm >> 3, lm & 7, S);
-                    else
-                        mt_times_q<6>(M, xbuf, lm, lm >> 3, lm & 7, S);
-                }
-                STAMP(6);
-            }
-        }
-        STAMP(7);
-
-        // ---- the next voxel starts from an all-zero LDS part of M
-        {
-            const int pe = __builtin_amdgcn_readfirstlane(S.p) < kLdsM ? __builtin_amdgcn_readfirstlane(S.p) : kLdsM;
-            if (pe > 0) {  // the LDS rows only: the whole area in 16-byte stores (five per lane) instead of a store per row
-                const double2 zero2 = {0.0, 0.0};
-                for (int e = 2 * lane; e < kLdsMDoubles; e += 2 * kW) *reinterpret_cast<double2 *>((double *)M.l + e) = zero2;
-            }
-        }
-        // ---- outputs: x by bin, rnorm = || [B; reg] x - [y; 0] ||_2 evaluated directly
-        double xb[kSlots] = {0, 0, 0, 0};
-        double rn;
-        if (status == 1) {
-            double tt = 0;
-            KArgs *K = kargs();
-            const double rc[5] = {K->rc[0], K->rc[1], K->rc[2], K->rc[3], K->rc[4]};
-            const int pf = __builtin_amdgcn_readfirstlane(S.p);
-            lds_order();
-            stage_bins(xbuf, ps, pf, lane, S.x, S.pidx);
-            const Win wl = load_win(xbuf + 2 + 2 * lane), wh = load_win(xbuf + 130 + 2 * lane);
-            double t[kSlots];
-            const double bx = bx_gather(Bl, xbuf, ps, pf, lane, [&]() { band_eval4<false>(K->rhb, wl, wh, rc, t); });
-            lds_order();
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if (binof(lane, s) < n) tt = fma(t[s], t[s], tt);  // rows >= n of R do not exist
-            xb[0] = wl.mid.x;
-            xb[1] = wl.mid.y;
-            xb[2] = wh.mid.x;
-            xb[3] = wh.mid.y;
-            const double r = lane < kBMeas ? yreg - bx : 0.0;
-            rn = sqrt(wave_sum(fma(r, r, tt)));
-        } else
-            rn = sqrt(wave_sum(lane < kBMeas ? yreg * yreg : 0.0));  // reference failure path: zeros, ||y_ext|| (nnls_solver.py:205-210)
-        {
-            KArgs *K = kargs();
-            if (status == kBail) {  // nothing is written: the general kernel solves this voxel from scratch
-                if (lane == 0) K->bail[atomicAdd(K->n_bail, 1)] = (int32_t)(K->vox_base + vox);
-            } else {
-                double *cv = K->coeff + (size_t)vox * n;
-#pragma unroll
-                for (int s = 0; s < kSlots; ++s) {
-                    const int j = binof(lane, s);
-                    if (j < n) cv[j] = xb[s];
-                }
-                if (lane == 0) {
-                    K->rnorm[vox] = rn;
-                    if (K->status) K->status[vox] = (int8_t)status;
-                    if (K->iters) K->iters[vox] = iteration;
-                }
-            }
-        }
-        STAMP(8);
-    }
-#ifdef PNX_NNLS_STAMP
-    if (threadIdx.x == 0 && blockIdx.x == 7)
-        printf("STAMP setup=%llu dual_bx=%llu dual_bt=%llu dual_reg=%llu cand+append=%llu sync=%llu alpha=%llu removal_head=%llu removal_rows=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[9], seg[10], seg[1], seg[2], seg[3], seg[4], seg[11], seg[5], seg[6], seg[7], seg[8]);
-    if (threadIdx.x == 0 && blockIdx.x == 0) printf("REJECTS so far=%llu\n", g_blk_rejects);
-    if (threadIdx.x == 0 && blockIdx.x == 7)
-        printf("COUNT voxels=%lld outer=%lld rejects=%lld removals=%lld rot_rows=%lld sum_p=%lld p_gt48=%lld p_gt64=%lld\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]);
-#endif
-}
+namespace pnx {
 
 #define PNX_HIPB(call)                                                                             \
     do {                                                                                           \
@@ -1222,25 +88,30 @@ __global__ void __launch_bounds__(kBlkWaves *kW) nnls_blk_kernel(const BlkArgs) 
         if (e__ != hipSuccess) return set_error(PNX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-static size_t blk_lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * (kScr + kLdsMDoubles)); }
-
 bool nnls_blk_applicable(const NnlsPlanData *P) {
-    return P->rhb != 0 && P->n_meas <= kBMeas && P->n_reg == P->n_bins && !getenv("PNX_NNLS_NO_BLK");
+    return P->rhb != 0 && P->n_meas <= blk2::kBMeas && P->n_reg == P->n_bins && !getenv("PNX_NNLS_NO_BLK");
 }
 
-// scratch of the block kernel: one workgroup of kBlkWaves waves per CU, kMSlab doubles of M per wave (zero initialised: the
-// block sweeps read whole blocks, also rows no voxel of this wave has written yet)
-int nnls_blk_plan_init(NnlsPlanData *P) {
-    PNX_HIPB(hipFuncSetAttribute((const void *)nnls_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes()));
+// scratch of the block kernels: one workgroup per CU, Variant::mslab doubles of M per wave (zero initialised: the block sweeps
+// read whole blocks, also rows no voxel of this wave has written yet)
+template <class V> static int blk_variant_init(const NnlsPlanData *P, int *groups, double **slab) {
+    PNX_HIPB(hipFuncSetAttribute(V::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds_bytes()));
     int occ = 0;
-    PNX_HIPB(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nnls_blk_kernel, kBlkWaves * kW, blk_lds_bytes()));
+    PNX_HIPB(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, V::kernel(), V::waves * kW, V::lds_bytes()));
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls block kernel does not fit on a CU");
-    P->blk_groups = occ * P->cus;
-    const size_t bytes = (size_t)P->blk_groups * kBlkWaves * kMSlab * sizeof(double);
-    PNX_HIPB(hipMalloc(&P->Mblk, bytes));
-    PNX_HIPB(hipMemset(P->Mblk, 0, bytes));
+    *groups = occ * P->cus;
+    const size_t bytes = (size_t)*groups * V::waves * V::mslab * sizeof(double);
+    PNX_HIPB(hipMalloc(slab, bytes));
+    PNX_HIPB(hipMemset(*slab, 0, bytes));
+    return PNX_OK;
+}
+int nnls_blk_plan_init(NnlsPlanData *P) {
+    int r;
+    if ((r = blk_variant_init<blk2::Variant>(P, &P->blk_groups, &P->Mblk))) return r;
+    if ((r = blk_variant_init<blk4::Variant>(P, &P->blk4_groups, &P->Mblk4))) return r;
     P->blk_bail_cap = (size_t)kAtyChunk;
-    PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));  // [0]: count, [1 ..]: voxel indices
+    PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));   // [0]: count, [1 ..]: voxel indices
+    PNX_HIPB(hipMalloc(&P->blk4_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));  // the same for what blk4 hands to the Gram-form kernel
     PNX_HIPB(hipMalloc(&P->route, sizeof(int32_t)));
     PNX_HIPB(hipMemset(P->route, 0, sizeof(int32_t)));
     return PNX_OK;
@@ -1259,31 +130,98 @@ __global__ void __launch_bounds__(256) bail_gather_kernel(int32_t *counters, con
     if (threadIdx.x == 0 && n > p) counters[1] = n;
 }
 
-// The pilot of a call.  This kernel pays for every voxel it hands over twice: ~130 outer iterations here, then the whole solve
-// again in the Gram-form kernel.  At the reference's regularisation strength one voxel in 10^4 is handed over; with a stronger
-// regulariser (order 1 with mu = 0.5: half of them) the plan was up to twice as slow as the Gram-form kernel alone
-// (profiles/nnls_mu_probe.py).  So a call of at least 4 kBlkPilot voxels solves its first kBlkPilot voxels here, and what that
-// pilot hands over decides the route of the rest ON THE DEVICE: both kernels are launched over the remaining voxels, and the
-// one that was not chosen leaves at once (one scalar load per wave).  The choice depends on the pilot's voxels only, never on
-// timing: the same call takes the same route every time.
+// The pilot of a call.  blk2 pays for every voxel it hands over twice: ~130 outer iterations there, then the whole solve again
+// in blk4.  At the reference's regularisation strength one voxel in 10^4 is handed over; with a stronger regulariser (order 1
+// with mu = 0.5: half of them) the two-pass plan loses to one pass of the wider kernel (profiles/nnls_mu_probe.py).  So a call
+// of at least 4 kBlkPilot voxels solves its first kBlkPilot voxels in blk2, and what that pilot hands over decides the route of
+// the rest ON THE DEVICE: both kernels are launched over the remaining voxels, and the one that was not chosen leaves at once
+// (one scalar load per wave).  The choice depends on the pilot's voxels only, never on timing: the same call takes the same
+// route every time.
 constexpr int64_t kBlkPilot = 12288;  // four voxels per resident wave of a full grid
 __global__ void blk_route_kernel(const int32_t *n_bail, int pilot, int permille, int32_t *route) {
     route[0] = ((long long)n_bail[0] * 1000 > (long long)permille * pilot) ? 1 : 0;
+}
+
+struct BlkCall {  // what every launch of a call shares
+    NnlsPlanData *P;
+    const double *y;
+    double *coeff, *rnorm;
+    int8_t *status;
+    int32_t *iters;
+    int max_iter;
+    hipStream_t stream;
+};
+// one launch of instantiation V over the voxels [off, off + c) of the call -- or, with a list, over list[0 .. min(*count, c))
+template <class V>
+static int blk_launch(const BlkCall &C, int64_t off, int64_t c, long long vox_base, int32_t *n_bail, int32_t *bail, const int32_t *route,
+                      int route_want, const int32_t *list, const int32_t *count) {
+    NnlsPlanData *P = C.P;
+    typename V::Args a;
+    a.y = C.y + (size_t)off * P->n_meas;
+    a.coeff = C.coeff + (size_t)off * P->n_bins;
+    a.rnorm = C.rnorm + off;
+    a.status = C.status ? C.status + off : nullptr;
+    a.iters = C.iters ? C.iters + off : nullptr;
+    a.G = P->G;
+    a.Bp = P->Bp;
+    a.Mglob = V::max_pos == 128 ? P->Mblk : P->Mblk4;
+    a.n_bail = n_bail;
+    a.bail = bail;
+    a.vox_base = vox_base;
+    a.queue = P->queue;
+    a.n_vox = c;
+    a.n_meas = P->n_meas;
+    a.n_bins = P->n_bins;
+    a.n_reg = P->n_reg;
+    a.max_iter = C.max_iter;
+    for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+    a.rhb = P->rhb;
+    a.test_rej_k = a.test_rej_n = 0;
+    if (const char *t = V::max_pos == 128 ? getenv("PNX_NNLS_TEST_REJECT") : nullptr) {  // the hand-over target runs without the hook (as the oracle's restatement of the hand-over does)
+        if (sscanf(t, "%d,%d", &a.test_rej_k, &a.test_rej_n) != 2 || a.test_rej_k < 1 || a.test_rej_n < 1) a.test_rej_k = a.test_rej_n = 0;
+    }
+    a.route = route;
+    a.route_want = route_want;
+    a.redo_list = list;
+    a.redo_count = count;
+    PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), C.stream));
+    const int groups = V::max_pos == 128 ? P->blk_groups : P->blk4_groups;
+    long long grid = (c + V::waves - 1) / V::waves;
+    if (grid > groups) grid = groups;
+    V::launch(dim3((unsigned)grid), V::lds_bytes(), C.stream, a);
+    PNX_HIPB(hipGetLastError());
+    return PNX_OK;
+}
+
+// The voxels list[0 .. min(*count, n_vox)) of a call through blk4 (every passive set of a 256-bin plan fits its 256 positions);
+// what blk4 itself gives up (a ninth rejected candidate in one outer iteration: test hook only) goes to the Gram-form kernel.
+int nnls_blk_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
+                         int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream) {
+    if (getenv("PNX_BLK_NO_WIDE"))  // (A/B) the round-4 hand-over target
+        return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, list, count, stream);
+    const BlkCall C{P, y_d, coeff_d, rnorm_d, status_d, iters_d, max_iter, stream};
+    PNX_HIPB(hipMemsetAsync(P->blk4_bail, 0, sizeof(int32_t), stream));
+    int r = blk_launch<blk4::Variant>(C, 0, n_vox, 0, P->blk4_bail, P->blk4_bail + 1, nullptr, 0, list, count);
+    if (r) return r;
+    return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk4_bail + 1, P->blk4_bail, stream);
 }
 
 int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                           int8_t *status_d, int32_t *iters_d, hipStream_t stream, const NnlsDefer *defer) {
     if (n_vox <= 0) return PNX_OK;
     if (n_vox >= (int64_t)1 << 31) return set_error(PNX_ERR_INVALID, "n_vox=%lld: at most 2^31 - 1 voxels per call", (long long)n_vox);
-    if (!defer) {
-        if ((size_t)n_vox > P->blk_bail_cap) {  // the hand-over list holds every voxel of a call in the worst case
-            (void)hipFree(P->blk_bail);  // synchronises: no earlier solve of this plan is still using it
-            P->blk_bail = nullptr;
-            P->blk_bail_cap = (size_t)n_vox;
-            PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
-        }
-        PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
+    if ((size_t)n_vox > P->blk_bail_cap) {  // the hand-over lists hold every voxel of a call in the worst case
+        (void)hipFree(P->blk_bail);  // synchronises: no earlier solve of this plan is still using them
+        (void)hipFree(P->blk4_bail);
+        P->blk_bail = P->blk4_bail = nullptr;
+        P->blk_bail_cap = (size_t)n_vox;
+        PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
+        PNX_HIPB(hipMalloc(&P->blk4_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));
     }
+    if (!defer) PNX_HIPB(hipMemsetAsync(P->blk_bail, 0, sizeof(int32_t), stream));
+    const BlkCall C{P, y_d, coeff_d, rnorm_d, status_d, iters_d, max_iter, stream};
+    int32_t *n_bail = defer ? defer->counters : P->blk_bail, *bail = defer ? defer->bail : P->blk_bail + 1;
+    const long long base = defer ? defer->base : 0;
     // ONE launch for the rest of the call: the kernel needs no per-chunk buffer (A^T y is never formed), and every launch ends in
     // a drain tail of ~1.4 ms (C4 volume: 488.2 ms in four launches of 2^20 voxels, 484.1 ms in one; PNX_BLK_CHUNK_LOG2 = 20
     // brings the launches of kAtyChunk voxels back)
@@ -1294,72 +232,44 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
     }
     // the pilot (see blk_route_kernel): in the first chunk of a call; the later chunks of a host-array call follow its route
     // (they run on the same stream, behind it)
-    int permille = 300;  // with the full grid behind the hand-over pass the block kernel wins up to ~30 % (profiles/nnls_mu_probe.py)
-    if (const char *t = getenv("PNX_BLK_ROUTE_PERMILLE")) permille = atoi(t);  // <= 0: no pilot, the block kernel for everything
+    int permille = 150;  // the two-pass plan (blk2, then blk4 for what it hands over) against one pass of blk4, by share handed over: equal at ~14 % (profiles/nnls_mu_probe.py)
+    if (const char *t = getenv("PNX_BLK_ROUTE_PERMILLE")) permille = atoi(t);  // <= 0: no pilot, blk2 first for everything
+    const bool wide_route = !getenv("PNX_BLK_NO_WIDE");
     const bool first = !defer || defer->base == 0;
     const int64_t pilot = (permille > 0 && first && n_vox >= 4 * kBlkPilot) ? kBlkPilot : 0;
     const int32_t *route = nullptr;
-    if (permille > 0 && defer && first && !pilot) PNX_HIPB(hipMemsetAsync(P->route, 0, sizeof(int32_t), stream));  // a short first chunk: the block kernel
+    if (permille > 0 && defer && first && !pilot) PNX_HIPB(hipMemsetAsync(P->route, 0, sizeof(int32_t), stream));  // a short first chunk: blk2
     if (permille > 0 && (pilot || (defer && !first))) route = P->route;
-    auto launch = [&](int64_t off, int64_t c, const int32_t *rt) -> int {
-        BlkArgs a;
-        a.y = y_d + (size_t)off * P->n_meas;
-        a.coeff = coeff_d + (size_t)off * P->n_bins;
-        a.rnorm = rnorm_d + off;
-        a.status = status_d ? status_d + off : nullptr;
-        a.iters = iters_d ? iters_d + off : nullptr;
-        a.G = P->G;
-        a.Bp = P->Bp;
-        a.Mglob = P->Mblk;
-        a.n_bail = defer ? defer->counters : P->blk_bail;
-        a.bail = defer ? defer->bail : P->blk_bail + 1;
-        a.vox_base = (defer ? defer->base : 0) + off;
-        a.queue = P->queue;
-        a.n_vox = c;
-        a.n_meas = P->n_meas;
-        a.n_bins = P->n_bins;
-        a.n_reg = P->n_reg;
-        a.max_iter = max_iter;
-        for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
-        a.rhb = P->rhb;
-        a.test_rej_k = a.test_rej_n = 0;
-        if (const char *t = getenv("PNX_NNLS_TEST_REJECT")) {
-            if (sscanf(t, "%d,%d", &a.test_rej_k, &a.test_rej_n) != 2 || a.test_rej_k < 1 || a.test_rej_n < 1) a.test_rej_k = a.test_rej_n = 0;
-        }
-        a.route = rt;
-        PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
-        long long grid = (c + kBlkWaves - 1) / kBlkWaves;
-        if (grid > P->blk_groups) grid = P->blk_groups;
-        hipLaunchKernelGGL(nnls_blk_kernel, dim3((unsigned)grid), dim3(kBlkWaves * kW), blk_lds_bytes(), stream, a);
-        PNX_HIPB(hipGetLastError());
-        return PNX_OK;
-    };
+    int r;
     if (pilot) {
-        int r = launch(0, pilot, nullptr);
-        if (r) return r;
-        hipLaunchKernelGGL(blk_route_kernel, dim3(1), dim3(1), 0, stream, defer ? defer->counters : P->blk_bail, (int)pilot, permille, P->route);
+        if ((r = blk_launch<blk2::Variant>(C, 0, pilot, base, n_bail, bail, nullptr, 0, nullptr, nullptr))) return r;
+        hipLaunchKernelGGL(blk_route_kernel, dim3(1), dim3(1), 0, stream, n_bail, (int)pilot, permille, P->route);
         PNX_HIPB(hipGetLastError());
         if (getenv("PNX_BLK_ROUTE_DEBUG")) {  // diagnostic (synchronises): what the pilot saw
             int32_t cnt = 0, rt = 0;
             PNX_HIPB(hipStreamSynchronize(stream));
-            PNX_HIPB(hipMemcpy(&cnt, defer ? defer->counters : P->blk_bail, sizeof(cnt), hipMemcpyDeviceToHost));
+            PNX_HIPB(hipMemcpy(&cnt, n_bail, sizeof(cnt), hipMemcpyDeviceToHost));
             PNX_HIPB(hipMemcpy(&rt, P->route, sizeof(rt), hipMemcpyDeviceToHost));
             fprintf(stderr, "pnx nnls pilot: %d of %d voxels handed over (%.1f %%), threshold %.1f %% -> %s\n", cnt, (int)pilot, 100.0 * cnt / (double)pilot,
-                    permille / 10.0, rt ? "Gram-form kernel" : "block kernel");
+                    permille / 10.0, rt ? (wide_route ? "four-slot block kernel" : "Gram-form kernel") : "block kernel");
         }
     }
     for (int64_t off = pilot; off < n_vox; off += chunk) {
         const int64_t c = (n_vox - off) < chunk ? (n_vox - off) : chunk;
-        int r = launch(off, c, route);
-        if (r) return r;
+        if ((r = blk_launch<blk2::Variant>(C, off, c, base + off, n_bail, bail, route, 0, nullptr, nullptr))) return r;
     }
-    if (route) {  // the same voxels through the Gram-form kernel -- which leaves at once unless the pilot chose it
-        int r = nnls_routed_device(P, n_vox - pilot, y_d + (size_t)pilot * P->n_meas, max_iter, coeff_d + (size_t)pilot * P->n_bins, rnorm_d + pilot,
-                                   status_d ? status_d + pilot : nullptr, iters_d ? iters_d + pilot : nullptr, route, stream);
-        if (r) return r;
+    if (route) {  // the same voxels through the other kernel -- which leaves at once unless the pilot chose it
+        if (wide_route) {
+            PNX_HIPB(hipMemsetAsync(P->blk4_bail, 0, sizeof(int32_t), stream));
+            if ((r = blk_launch<blk4::Variant>(C, pilot, n_vox - pilot, pilot, P->blk4_bail, P->blk4_bail + 1, route, 1, nullptr, nullptr))) return r;
+            // what blk4 gives up (test hook only): the Gram-form kernel, indices relative to this call's arrays
+            if ((r = nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk4_bail + 1, P->blk4_bail, stream))) return r;
+        } else if ((r = nnls_routed_device(P, n_vox - pilot, y_d + (size_t)pilot * P->n_meas, max_iter, coeff_d + (size_t)pilot * P->n_bins, rnorm_d + pilot,
+                                           status_d ? status_d + pilot : nullptr, iters_d ? iters_d + pilot : nullptr, route, stream)))
+            return r;
     }
-    // voxels whose passive set outgrew this kernel (about one in 10^4 on the reference workload, and the slowest ones: a single
-    // launch for the whole call, so that their long solves overlap): the general kernel, from scratch
+    // voxels whose passive set outgrew blk2 (about one in 10^4 on the reference workload, and the slowest ones: a single
+    // launch for the whole call, so that their long solves overlap): blk4, from scratch
     if (defer) {
         // a host-array call made of several chunks: this chunk's handed-over voxels keep their signal rows in the side buffer,
         // and ONE pass at the end of the call solves them all (each such pass costs ~8 ms whatever the number of voxels:
@@ -1369,7 +279,7 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         PNX_HIPB(hipGetLastError());
         return PNX_OK;
     }
-    return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk_bail + 1, P->blk_bail, stream);
+    return nnls_blk_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, P->blk_bail + 1, P->blk_bail, stream);
 }
 
 }  // namespace pnx

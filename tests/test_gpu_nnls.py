@@ -458,10 +458,11 @@ def _strong_regulariser():
 
 
 def test_pilot_routes_a_strong_regulariser_to_the_gram_form_kernel(gpu, oracle, monkeypatch, capfd):
-    """The block kernel pays twice for a voxel it hands over (passive set beyond 128 positions).  A call of >= 4 x 12 288 voxels
-    therefore solves a pilot of 12 288 first, and when more than 30 % of those are handed over the rest of the call goes to the
-    Gram-form kernel directly -- decided on the device, from the pilot's voxels only.  Same results as the block kernel for
-    everything (PNX_BLK_ROUTE_PERMILLE=0) and as the oracle; the reference's own regulariser stays on the block kernel."""
+    """The two-slot block kernel pays twice for a voxel it hands over (passive set beyond 128 positions).  A call of >= 4 x 12 288
+    voxels therefore solves a pilot of 12 288 first, and when more than 15 % of those are handed over the rest of the call goes to
+    the four-slot instantiation (256 positions) directly -- decided on the device, from the pilot's voxels only.  Same results as
+    the two-slot kernel first for everything (PNX_BLK_ROUTE_PERMILLE=0) and as the oracle; the reference's own regulariser stays
+    on the two-slot kernel."""
     from pyneapple_amd import synth
 
     basis, reg = _strong_regulariser()
@@ -470,7 +471,7 @@ def test_pilot_routes_a_strong_regulariser_to_the_gram_form_kernel(gpu, oracle, 
     capfd.readouterr()
     routed = gpu.nnls(basis, reg, y, 250)
     err = capfd.readouterr().err
-    assert "pnx nnls pilot" in err and "-> Gram-form kernel" in err, err
+    assert "pnx nnls pilot" in err and "-> four-slot block kernel" in err, err
     monkeypatch.setenv("PNX_BLK_ROUTE_PERMILLE", "0")
     blk = gpu.nnls(basis, reg, y, 250)
     assert "pnx nnls pilot" not in capfd.readouterr().err
@@ -514,7 +515,7 @@ def test_pilot_route_holds_for_the_later_chunks_of_a_host_call(gpu, monkeypatch,
     capfd.readouterr()
     many = plan.solve(y, 250)
     err = capfd.readouterr().err
-    assert err.count("pnx nnls pilot") == 1 and "-> Gram-form kernel" in err, err
+    assert err.count("pnx nnls pilot") == 1 and "-> four-slot block kernel" in err, err
     for k in ("coefficients", "residual", "status", "iters"):
         np.testing.assert_array_equal(many[k], one[k], err_msg=k)
     many32 = plan.solve(y.astype(np.float32), 250)
@@ -540,7 +541,7 @@ def test_many_handed_over_voxels_go_through_the_side_buffer_in_batches(gpu, monk
     monkeypatch.setenv("PNX_BLK_ROUTE_DEBUG", "1")
     capfd.readouterr()
     one = plan.solve(y, 250)
-    assert "-> block kernel" in capfd.readouterr().err  # 5 - 10 % handed over: below the pilot's threshold
+    assert "-> block kernel" in capfd.readouterr().err  # 5 - 10 % handed over: below the pilot's threshold of 15 %
     n_over = int(((one["coefficients"] > 0).sum(axis=1) > 128).sum())
     assert n_over > 3000
     monkeypatch.setenv("PNX_NNLS_HOST_CHUNK", "50000")
