@@ -171,12 +171,14 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  *   basis (n_meas, n_bins) row-major host;  reg (n_reg, n_bins) row-major host or NULL (n_reg = 0).
  * The plan picks the kernel; all of them walk the Lawson-Hanson path of scipy.optimize.nnls (same iteration counts):
  *   - reg = one of the reference's banded matrices (model_functions/nnls.py:46-85, orders 1-3) and n_meas <= 32 (every
- *     configuration the reference ships): basis resident in LDS, residual-form dual (csrc/pnx_nnls_blk.hip).  That kernel
- *     holds 128 passive-set positions; a voxel that wants more is solved again by the Gram-form kernel in one pass behind the
- *     call (the plan keeps 1 GB of per-wave slabs for it).  With a regulariser several times stronger than the reference's
- *     mu = 0.02 that concerns many voxels, so a call of >= 49 152 voxels solves a pilot of its first 12 288 and, when more than
- *     30 % of those are handed over, the rest of the call goes to the Gram-form kernel directly -- decided on the device, from
- *     the pilot's voxels only (PNX_BLK_ROUTE_PERMILLE = 300; 0: no pilot);
+ *     configuration the reference ships): basis resident in LDS, residual-form dual (csrc/pnx_nnls_blk.hip).  Its first
+ *     instantiation holds 128 passive-set positions (twelve voxels in flight per CU); a voxel that wants more is solved again
+ *     by a second instantiation with 256 positions (eight per CU) in one pass behind the call.  With a regulariser several
+ *     times stronger than the reference's mu = 0.02 that concerns many voxels, so a call of >= 49 152 voxels solves a pilot of
+ *     its first 12 288 and, when more than 15 % of those are handed over, the rest of the call goes to the second instantiation
+ *     directly -- decided on the device, from the pilot's voxels only (PNX_BLK_ROUTE_PERMILLE = 150; 0: no pilot).  A plan keeps
+ *     ~1.8 GB of per-wave slabs on the device for the three kernels involved (0.2 + 0.55 GB the two instantiations, 1 GB the
+ *     Gram-form kernel that remains the last resort behind them);
  *   - no regulariser / an all-zero one (reg_order = 0, the reference default): QR form (pnx_nnls_qr.hip) -- Q and R in LDS
  *     up to 32 measurements, in a per-wave global slab from 33 to 128 (264 KB per resident wave, allocated on the first
  *     solve of such a plan; up to round 3 more than 64 measurements were refused); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and

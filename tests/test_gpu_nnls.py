@@ -457,7 +457,7 @@ def _strong_regulariser():
     return basis, reg
 
 
-def test_pilot_routes_a_strong_regulariser_to_the_gram_form_kernel(gpu, oracle, monkeypatch, capfd):
+def test_pilot_routes_a_strong_regulariser_to_the_four_slot_kernel(gpu, oracle, monkeypatch, capfd):
     """The two-slot block kernel pays twice for a voxel it hands over (passive set beyond 128 positions).  A call of >= 4 x 12 288
     voxels therefore solves a pilot of 12 288 first, and when more than 15 % of those are handed over the rest of the call goes to
     the four-slot instantiation (256 positions) directly -- decided on the device, from the pilot's voxels only.  Same results as
