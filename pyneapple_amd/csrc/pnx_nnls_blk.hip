@@ -56,6 +56,7 @@
 #define PNX_BLK_NS blk2
 #define PNX_BLK_KERNEL nnls_blk_kernel
 #define PNX_BLK_PS 2
+#define PNX_BLK_ROWS2D 48
 #ifndef PNX_BLK_WAVES
 #define PNX_BLK_WAVES 12
 #endif
@@ -66,17 +67,20 @@
 #undef PNX_BLK_NS
 #undef PNX_BLK_KERNEL
 #undef PNX_BLK_PS
+#undef PNX_BLK_ROWS2D
 #undef PNX_BLK_WAVES
 #undef PNX_BLK_LDS_ROWS
 #define PNX_BLK_NS blk4
 #define PNX_BLK_KERNEL nnls_blk4_kernel
 #define PNX_BLK_PS 4
+#define PNX_BLK_ROWS2D 64
 #define PNX_BLK_WAVES 8
 #define PNX_BLK_LDS_ROWS 32
 #include "pnx_nnls_blk_kernel.hpp"
 #undef PNX_BLK_NS
 #undef PNX_BLK_KERNEL
 #undef PNX_BLK_PS
+#undef PNX_BLK_ROWS2D
 #undef PNX_BLK_WAVES
 #undef PNX_BLK_LDS_ROWS
 

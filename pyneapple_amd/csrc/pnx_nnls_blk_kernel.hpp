@@ -8,7 +8,10 @@ constexpr int kBMeas = 32;                  // measurements the LDS copy of the 
 constexpr int kBStride = kNnlsMaxBins + 2;  // even: rows stay 16-byte aligned for ds_read_b128; a column gather (lane = measurement) is 2-way bank conflicted
 constexpr int kBlkWaves = PNX_BLK_WAVES;    // waves per workgroup = voxels in flight per CU (12: 168 registers per wave, no scratch; 16 waves at 128
                                             // registers measured 7.2 against 8.2 M voxels/s; the four-slot instantiation: 8 waves, 256 registers)
-constexpr int kRows2D = 48;                 // rows / columns of M handled block-wise (6 x 6 blocks of 8 x 8)
+constexpr int kRows2D = PNX_BLK_ROWS2D;     // rows / columns of M handled block-wise: 48 (6 x 6 blocks of 8 x 8; two-slot instantiation: eight block rows
+                                            // cost it 160 bytes of scratch, measured) or 64 (four-slot instantiation: 256 registers per lane)
+constexpr int kNIMax = kRows2D / 8;
+static_assert(kRows2D == 48 || kRows2D == 64, "block-wise part of M: six or eight block rows");
 constexpr int kPS = PNX_BLK_PS;             // register slots of a position-indexed vector: 2 (positions < 128) or 4 (< 256: every passive set fits)
 constexpr int kMaxPos = kPS * kW;           // a voxel whose passive set wants to grow beyond that is handed to pnx_nnls.hip
 constexpr int kXbuf = (2 + kNnlsMaxBins + 2 + 4) > 2 * kMaxPos + 8 ? (2 + kNnlsMaxBins + 2 + 4) : 2 * kMaxPos + 8;  // x by bin with its halo and four spare doubles -- or the (c, s) pairs of a removal, one per position
@@ -521,7 +524,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     double a1[kPS];    // l^T M by position
 #pragma unroll
     for (int s = 0; s < kPS; ++s) a1[s] = 0;
-    if (NI == 6 && p > kRows2D) {
+    if (NI == kNIMax && p > kRows2D) {
         double g[kPS];
 #pragma unroll
         for (int s = 0; s < kPS; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
@@ -532,7 +535,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #pragma unroll
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
-                m[s] = (k <= i) ? M.g[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end: masked
+                m[s] = (s < si || k <= i) ? M.g[CK(rbase + k, kMSlab, 5, i)] : 0.0;  // past the row end (last slot of the row only): masked
                 part = fma(m[s], g[s], part);
             }
             const double li = wave_sum(part);
@@ -555,7 +558,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
                 part[r] = 0;
 #pragma unroll
                 for (int s = 0; s <= si; ++s) {
-                    m[r][s] = (lane + kW * s <= i + r) ? m[r][s] : 0.0;
+                    m[r][s] = (s < si || lane + kW * s <= i + r) ? m[r][s] : 0.0;  // only the row's last slot reaches beyond its end
                     part[r] = fma(m[r][s], g[s], part[r]);
                 }
             }
@@ -713,7 +716,7 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
     S.z[0] = reduce_scatter_a<NI>(zK, la);
 #pragma unroll
     for (int s = 1; s < kPS; ++s) S.z[s] = 0;
-    if (NI == 6 && p > kRows2D) {
+    if (NI == kNIMax && p > kRows2D) {
         auto one = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             const double a = rl(S.q[si], i & 63);
@@ -722,7 +725,7 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
             for (int s = 0; s <= si; ++s) {
                 const int k = lane + kW * s;
                 const double m0 = M.g[CK(rbase + k, kMSlab, 5, i)];
-                S.z[s] += a * ((k <= i) ? m0 : 0.0);
+                S.z[s] += a * ((s < si || k <= i) ? m0 : 0.0);
             }
         };
         auto four = [&](int i, auto T) {
@@ -738,7 +741,7 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
             for (int r = 0; r < 4; ++r) {
                 const double a = rl(S.q[si], (i + r) & 63);
 #pragma unroll
-                for (int s = 0; s <= si; ++s) S.z[s] += a * ((lane + kW * s <= i + r) ? m[r][s] : 0.0);
+                for (int s = 0; s <= si; ++s) S.z[s] += a * ((s < si || lane + kW * s <= i + r) ? m[r][s] : 0.0);
             }
         };
         for_pos4n<kPS>(kRows2D, p, four, one);
@@ -844,8 +847,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                         r = candidate<2>(Gp, M, ps, rejlist, lc, w, S);
                     else if (nI <= 4)
                         r = candidate<4>(Gp, M, ps, rejlist, lc, w, S);
-                    else
+                    else if (nI <= 6 || kNIMax == 6)
                         r = candidate<6>(Gp, M, ps, rejlist, lc, w, S);
+                    else
+                        r = candidate<kNIMax>(Gp, M, ps, rejlist, lc, w, S);
                     r = __builtin_amdgcn_readfirstlane(r);
                     if (r == 2) {
                         COUNT(2, 1);
@@ -1123,8 +1128,10 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                         mt_times_q<2>(M, xbuf, lm, lm >> 3, lm & 7, S);
                     else if (nI <= 4)
                         mt_times_q<4>(M, xbuf, lm, lm >> 3, lm & 7, S);
-                    else
+                    else if (nI <= 6 || kNIMax == 6)
                         mt_times_q<6>(M, xbuf, lm, lm >> 3, lm & 7, S);
+                    else
+                        mt_times_q<kNIMax>(M, xbuf, lm, lm >> 3, lm & 7, S);
                 }
                 STAMP(6);
             }
