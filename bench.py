@@ -17,8 +17,11 @@ RCCL only carries the barrier and the MAX-reduce of the timed region.  value = v
 child processes, spawned before anything in this process touches the GPU.  Rank 0 prints ONE JSON line.
 
 `value` is the device-resident rate (inputs in HBM when the timed region starts, as the bench contract asks);
-`host_mode` (N = 1) is the PCIe-inclusive rate of the same work through PNX_MEM_HOST -- numpy arrays in, numpy arrays
-out, what the reference's fitter hands its solver (fitters/pixelwise.py:91-96).
+`host_mode` (every rank on its shard, max over ranks) is the PCIe-inclusive rate of the same work through PNX_MEM_HOST --
+numpy arrays in, numpy arrays out, what the reference's fitter hands its solver (fitters/pixelwise.py:91-96).
+`noise_sweep` (N = 1): both fits on 2^20 voxels of the same volume at 0 / 1 / 5 % noise -- the rates depend on the data (the
+benchmark's volume carries 1 %): the curve fit slows down with the noise (longer trust-region walks, lanes out of step), the
+NNLS speeds up (smaller supports).
 """
 from __future__ import annotations
 
@@ -62,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-mode", action="store_true", help="skip the PCIe-inclusive host-pointer legs")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-passes-in-flight leg of the curve fit")
+    ap.add_argument("--no-noise-sweep", action="store_true", help="skip the 0 / 1 / 5 % noise sweep of both fits (N = 1, 2^20 voxels each)")
     ap.add_argument("--voxels", type=int, default=0, help="override the voxels of the volume (debug; marks the line invalid)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="(launcher test) this rank exits with code 3 at start-up")
     ap.add_argument("--launch-check", action="store_true",
@@ -195,7 +199,7 @@ def volume_rows(workload, args, rank, world):
 
 
 class CurvefitLeg:
-    def __init__(self, workload, device, jac, want_pcov, n_vox_total, rows):
+    def __init__(self, workload, device, jac, want_pcov, n_vox_total, rows, sigma=0.01):
         import torch
         from pyneapple_amd import api, synth
 
@@ -209,7 +213,7 @@ class CurvefitLeg:
         n = len(self.names)
         self.n = n
         self.jac, self.want_pcov = jac, want_pcov
-        self.b, self.y = synth.make_torch_rows(model, rows[0], rows[1], n_b, device, sigma=0.01)
+        self.b, self.y = synth.make_torch_rows(model, rows[0], rows[1], n_b, device, sigma=sigma)
         self.opts = api.make_opts(model, n_b, max_nfev=250, ftol=1e-8, jac=jac)
         self.popt = torch.empty((n, self.n_vox), dtype=torch.float64, device=device)
         self.pcov = torch.empty((self.n_vox, n, n), dtype=torch.float64, device=device) if want_pcov else None
@@ -336,7 +340,7 @@ class CurvefitLeg:
 
 
 class NnlsLeg:
-    def __init__(self, device, n_vox_total, rows):
+    def __init__(self, device, n_vox_total, rows, sigma=0.01):
         import torch
         from pyneapple_amd import api, synth
 
@@ -350,7 +354,7 @@ class NnlsLeg:
         self.cfg = cfg
         self.bins, self.basis, self.reg = synth.nnls_matrices(n_b, cfg)
         self.plan = api.NnlsPlan(self.basis, self.reg, device.index)
-        _, self.y = synth.make_torch_rows("tri_reduced", rows[0], rows[1], n_b, device, sigma=0.01, scale=1000.0)
+        _, self.y = synth.make_torch_rows("tri_reduced", rows[0], rows[1], n_b, device, sigma=sigma, scale=1000.0)
         nb = cfg["n_bins"]
         self.coeff = torch.empty((self.n_vox, nb), dtype=torch.float64, device=device)
         self.rnorm = torch.empty(self.n_vox, dtype=torch.float64, device=device)
@@ -688,6 +692,35 @@ WORKLOAD_TEXT = {
 }
 
 
+NOISE_SWEEP_SIGMAS = (0.0, 0.01, 0.05)
+NOISE_SWEEP_VOXELS = 1 << 20
+
+
+def noise_sweep(device, torch, jac="fd"):
+    """Data dependence of both rates: rows [0, 2^20) of the benchmark's volume re-drawn at sigma = 0 / 1 % / 5 % (same seed, same
+    ground truth), each fit device resident, one warm-up and the best of two passes (a pass of 2^20 voxels: ~9 ms for the curve
+    fit, ~120 ms for the NNLS; < 2 s in all).  voxels/s."""
+    out = {"sigma": list(NOISE_SWEEP_SIGMAS), "voxels": NOISE_SWEEP_VOXELS, "c3_voxels_per_s": [], "c4_voxels_per_s": []}
+    for key, make in (("c3_voxels_per_s", lambda s: CurvefitLeg("triexp", device, jac, True, NOISE_SWEEP_VOXELS, (0, NOISE_SWEEP_VOXELS), sigma=s)),
+                      ("c4_voxels_per_s", lambda s: NnlsLeg(device, NOISE_SWEEP_VOXELS, (0, NOISE_SWEEP_VOXELS), sigma=s))):
+        for s in NOISE_SWEEP_SIGMAS:
+            leg = make(s)
+            leg.step()
+            torch.cuda.synchronize()
+            best = float("inf")
+            for _ in range(2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                leg.step()
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e-3)
+            out[key].append(NOISE_SWEEP_VOXELS / best)
+            del leg
+            torch.cuda.empty_cache()
+    return out
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -704,7 +737,10 @@ def main(argv=None):
         return 3
     n_total, rows = volume_rows(args.workload, args, rank, world)
     if args.launch_check:
-        print(json.dumps({"rank": rank, "world": world, "local_rank": local, "rows": rows, "n_vox_total": n_total}), flush=True)
+        # the launcher, the row split and (N > 1) the CPU slice a rank would pin itself to -- without touching the GPU: the N = 8
+        # the driver uses can be rehearsed anywhere (a GPU box admits at most six processes on its card)
+        aff = pin_rank_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.environ.get("PNX_BENCH_SHARE_GPU") == "1") if world > 1 else None
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local, "rows": rows, "n_vox_total": n_total, "affinity": aff}), flush=True)
         time.sleep(float(os.environ.get("PNX_BENCH_LAUNCH_HOLD", "0")))  # launcher test: a rank that would wait for its peers
         return 0
 
@@ -813,12 +849,13 @@ def main(argv=None):
         torch.cuda.empty_cache()
         n2, rows2 = volume_rows("nnls", args, rank, world)
         leg2 = NnlsLeg(device, n2, rows2)
-        steps2 = max(1, min(args.steps, 2))
+        steps2 = 3  # a C4 pass is ~0.45 s: three timed passes whatever --steps says (min / median of the passes are reported beside the mean)
         dt2, k2 = timed(leg2, steps2, 1 if args.warmup else 0, world, dist, torch)
         k2avg = float(np.mean(k2)) * 1e-3
         ach2 = leg2.bytes_per_voxel * leg2.n_vox / k2avg / 1e9
         sec = {"workload": WORKLOAD_TEXT["nnls"], "value": n2 * steps2 / dt2,
-               "unit": "voxels/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3, "check": leg2.check(),
+               "unit": "voxels/s", "steps": steps2, "ms_per_step": dt2 / steps2 * 1e3,
+               "ms_per_step_min": float(np.min(k2)), "ms_per_step_median": float(np.median(k2)), "check": leg2.check(),
                "roofline": {"bound": "hbm", "kernel": NNLS_KERNEL, "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach2 / HBM_PEAK_GBS,
                             "traffic": nnls_traffic(leg2.n_vox) if (not args.voxels and world == 1) else None,
@@ -852,6 +889,8 @@ def main(argv=None):
         time.sleep(1.0)
         out["roofline_sweep"] = sweep_roofline(device, torch, args.voxels)
         out["roofline_mfma"] = mfma_roofline(device, torch)
+        if world == 1 and not args.no_noise_sweep:
+            out["noise_sweep"] = noise_sweep(device, torch, args.jac)
     if world > 1:
         aff = [None] * world
         dist.all_gather_object(aff, affinity)
@@ -871,7 +910,8 @@ SCALAR_KEYS = ("nnls_voxels_per_s", "nnls_ms_per_step", "c3_host_voxels_per_s", 
 
 def finalize(out: dict, workload: str = "triexp") -> dict:
     """The bench line in the order a truncating reader needs it: the contract's keys, then the five scalars of the metric's
-    other half (resident NNLS rate, both PCIe-inclusive rates, the two-in-flight throughput), then roofline / cpu_baseline,
+    other half (resident NNLS rate, both PCIe-inclusive rates, the two-in-flight throughput), the noise sweep of both rates and
+    the min / median of the NNLS passes, then roofline / cpu_baseline,
     then the detail objects; every prose string (`note`, `workload`, `mode`) moves to ONE trailing `notes` object keyed by its
     path.  Pure function (tests/test_bench_line.py runs it on a committed line)."""
     out = json.loads(json.dumps(out))  # deep copy, JSON types only
@@ -896,6 +936,10 @@ def finalize(out: dict, workload: str = "triexp") -> dict:
     strip(out, [])
     final = {k: out[k] for k in HEAD_KEYS if k in out}
     final.update(scal)
+    if "noise_sweep" in out:  # the data dependence of both rates belongs next to them (inside the first 2 000 bytes)
+        final["noise_sweep"] = out["noise_sweep"]
+    if nn.get("ms_per_step_min") is not None:
+        final["nnls_ms_per_step_min"], final["nnls_ms_per_step_median"] = nn["ms_per_step_min"], nn["ms_per_step_median"]
     for k in ("roofline", "cpu_baseline", "config", "check"):
         if k in out:
             final[k] = out[k]

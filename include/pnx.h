@@ -29,6 +29,14 @@
  *   - The caller allocates all outputs.  The library owns only device scratch.
  *   - Per-voxel numerical failure never produces an error code: it is reported in `status[]`
  *     with the reference's sentinel outputs (curvefit.py:308-317, nnls_solver.py:201-210).
+ *   - Environment.  A production process reads five variables, none of which changes a result or selects a kernel:
+ *     PNX_STREAM_CACHE_MB (staging slab a host-array curve fit keeps per device, default 8192), PNX_COPY_PIECE_MB (32) and
+ *     PNX_COPY_THREADS (4) of pnx_upload / pnx_download, PNX_HOST_TOUCHERS and PNX_STREAM_OUT_THREADS (helper threads of a
+ *     host-array call).  Everything else the sources know -- A/B switches between kernels (PNX_NNLS_NO_BLK, PNX_BLK_NO_WIDE,
+ *     PNX_NNLS_NO_QR, PNX_NNLS_NO_MFMA, PNX_BLK_ROUTE_PERMILLE ...), chunk sizes of the host pipelines, trace output and the
+ *     test hook PNX_NNLS_TEST_REJECT (forces rejected candidate columns in the NNLS block kernel) -- is read ONLY when the
+ *     process was started with PNX_ENABLE_TEST_HOOKS=1 (looked at once, at the first query); the test-suite and the
+ *     profiling scripts set it, bench.py and the plugin never do.
  */
 #ifndef PNX_H
 #define PNX_H
@@ -39,8 +47,15 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the functions declared here are its only exports. */
+#if defined(__GNUC__) || defined(__clang__)
+#define PNX_API __attribute__((visibility("default")))
+#else
+#define PNX_API
+#endif
+
 #define PNX_VERSION_MAJOR 0
-#define PNX_VERSION_MINOR 1
+#define PNX_VERSION_MINOR 2
 #define PNX_MAX_PARAMS 8  /* max model parameters (free + fixed) */
 #define PNX_MAX_BVALUES 128
 
@@ -101,41 +116,50 @@ typedef struct pnx_curvefit_opts {
     int32_t t1_mode;                     /* 0 none; 1 T1: S*(1-exp(-TR/T1)); 2 STEAM: additionally *exp(-TM/T1).
                                             T1 is then one more model parameter, appended last
                                             (model_functions/multiexp.py:210-241, each model class appends "T1" to its names) */
-    int32_t reserved0;
+    int32_t absolute_sigma;              /* curve_fit(absolute_sigma=True): pcov is returned unscaled instead of
+                                            multiplied by 2 cost / (n_b - n_free) (scipy:_minpack_py.py:1057-1063) */
     double tr;                           /* repetition time, same unit as T1 */
     double tm;                           /* mixing time (STEAM) */
     double ftol;                         /* reference's tol (curvefit.py:304) */
     double xtol;                         /* SciPy default 1e-8 */
     double gtol;                         /* SciPy default 1e-8 */
+    const double *sigma;                 /* NULL, or (n_b,) doubles on the HOST (also for the _f32 entry point): curve_fit's 1-D
+                                            `sigma`, shared by all voxels -- the two keyword arguments the reference's solver
+                                            names and forwards (curvefit.py:33, 295-306).  Residual and Jacobian rows are
+                                            multiplied by 1 / sigma_i (_minpack_py.py:958-960, 545-562); cost is the weighted
+                                            0.5 * sum.  A scalar sigma is n_b equal entries; a 2-D sigma (covariance matrix of
+                                            the measurements) is not implemented */
+    const int32_t *queue_order;          /* NULL, or n_vox int32 on the DEVICE, a permutation of 0 .. n_vox - 1 (PNX_MEM_DEVICE
+                                            calls only, PNX_ERR_INVALID otherwise): the kernel's k-th queue pull fits voxel
+                                            queue_order[k].  Results do not depend on the order (a voxel's arithmetic is its own);
+                                            the run time does: a pass ends in the longest fits that were started last, so a caller
+                                            with a predictor of the evaluation counts -- the nfev map of a previous fit of the
+                                            same volume (refits, the second step of the reference's SegmentedFitter) or of the
+                                            previous level of the IDEAL pyramid (fitters/ideal.py:150-190) -- passes them longest
+                                            first (pnx_queue_order_f64 builds the permutation).  The array must stay valid until
+                                            the call's work on `stream` has finished */
 } pnx_curvefit_opts;
 
-int pnx_version(void);
+PNX_API int pnx_version(void);
 /* Number of visible HIP devices (0 if none); never fails. */
-int pnx_device_count(void);
+PNX_API int pnx_device_count(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf; returns its length. */
-int pnx_last_error(char *buf, int n);
+PNX_API int pnx_last_error(char *buf, int n);
 /* Number of parameters of a model without the optional T1 parameter, or PNX_ERR_INVALID. */
-int pnx_model_n_params(int model);
+PNX_API int pnx_model_n_params(int model);
 
 /*
- * PNX_MEM_HOST curve-fit calls keep one device staging slab (the volume's signal and results,
- * up to PNX_STREAM_CACHE_MB, default 8192), a pinned control block and their streams per device for the next call.
- * This frees them; PNX_ERR_INVALID while such a call is running on the device.
+ * Device memory the library keeps between calls, per device: (i) PNX_MEM_HOST curve-fit calls keep one staging slab (the
+ * volume's signal and results, up to PNX_STREAM_CACHE_MB, default 8192), a pinned control block and their streams for the next
+ * call; (ii) the NNLS plans of the reference's regularised configurations share ONE set of slabs for the kernels behind their
+ * first pass (1.55 GB, see pnx_nnls_plan_create), which stays allocated when the last plan is destroyed.
+ * This frees both -- (i) unless such a call is running on the device (PNX_ERR_INVALID), (ii) unless a plan still exists.
  */
-int pnx_release_staging(int device);
+PNX_API int pnx_release_staging(int device);
 
-/*
- * Queue order of the calling thread's NEXT device-mode curve fit (PNX_MEM_DEVICE): `order_device` is a device array of n_vox
- * int32, a permutation of 0 .. n_vox - 1; the kernel's k-th queue pull fits voxel order[k].  Results do not depend on the
- * order (a voxel's arithmetic is its own); the run time does: a pass ends in the longest fits that were started last, so a
- * caller that has a predictor of the evaluation counts -- the nfev map of a previous fit of the same volume (refits, the
- * second step of the reference's SegmentedFitter) or of the previous level of the IDEAL pyramid (fitters/ideal.py:150-190)
- * -- passes them longest first.  NULL (the default after every call) = ascending voxel index.
- */
-int pnx_curvefit_queue_order(const int32_t *order_device);
 /* order (n int32, device) = the voxel indices by descending key (n doubles, device), equal keys in index order: the queue order
- * for pnx_curvefit_queue_order from a predicted evaluation count per voxel.  Synchronises `stream`. */
-int pnx_queue_order_f64(const double *key_device, int64_t n, int32_t *order_device, int device, void *stream);
+ * for pnx_curvefit_opts::queue_order from a predicted evaluation count per voxel.  Synchronises `stream`. */
+PNX_API int pnx_queue_order_f64(const double *key_device, int64_t n, int32_t *order_device, int device, void *stream);
 
 /*
  * Batched bounded non-linear least squares, fp64, results matching SciPy 1.15 curve_fit(method="trf").
@@ -150,7 +174,7 @@ int pnx_queue_order_f64(const double *key_device, int64_t n, int32_t *order_devi
  *   status (n_vox) int8, nfev (n_vox) int32, cost (n_vox) = 0.5*sum(res^2): out, each may be NULL
  *          (PNX_MEM_DEVICE: status and cost are required when pcov is requested)
  */
-int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const double *b, const double *y,
+PNX_API int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const double *b, const double *y,
                            const double *p0, const double *lo, const double *hi, const double *fixed,
                            double *popt, double *pcov, int8_t *status, int32_t *nfev, double *cost,
                            int mem, int device, void *stream);
@@ -161,7 +185,7 @@ int pnx_curvefit_batch_f64(const pnx_curvefit_opts *opts, int64_t n_vox, const d
  * reference computes for a float32 image -- curve_fit casts ydata to float64 (scipy:_minpack_py.py:930) -- without
  * the host-side float64 copy and with half the PCIe traffic.  SURVEY.md 8b: "T in {f32, f64} via suffix".
  */
-int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const float *b, const float *y, const float *p0,
+PNX_API int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const float *b, const float *y, const float *p0,
                            const float *lo, const float *hi, const float *fixed, float *popt, float *pcov,
                            int8_t *status, int32_t *nfev, float *cost, int mem, int device, void *stream);
 
@@ -176,9 +200,12 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  *     by a second instantiation with 256 positions (eight per CU) in one pass behind the call.  With a regulariser several
  *     times stronger than the reference's mu = 0.02 that concerns many voxels, so a call of >= 49 152 voxels solves a pilot of
  *     its first 12 288 and, when more than 15 % of those are handed over, the rest of the call goes to the second instantiation
- *     directly -- decided on the device, from the pilot's voxels only (PNX_BLK_ROUTE_PERMILLE = 150; 0: no pilot).  A plan keeps
- *     ~1.8 GB of per-wave slabs on the device for the three kernels involved (0.2 + 0.55 GB the two instantiations, 1 GB the
- *     Gram-form kernel that remains the last resort behind them);
+ *     directly -- decided on the device, from the pilot's voxels only.  Device memory: a plan owns 0.2 GB of per-wave
+ *     slabs (the first instantiation); the slabs of the two kernels behind it -- 0.55 GB the second instantiation, 1 GB the
+ *     Gram-form kernel that remains the last resort -- exist ONCE per device and are shared by all such plans on it (N plans:
+ *     1.55 + N x 0.2 GB; their uses are ordered on the device by events, calls stay asynchronous; pnx_release_staging frees the
+ *     set once no plan is left).  Passive sets of up to 16 bins evaluate the dual in Gram form, w = A^T y - G[:, P] x_P (16 rows
+ *     of G out of L2 instead of the 64 KB basis out of LDS), larger ones in residual form;
  *   - no regulariser / an all-zero one (reg_order = 0, the reference default): QR form (pnx_nnls_qr.hip) -- Q and R in LDS
  *     up to 32 measurements, in a per-wave global slab from 33 to 128 (264 KB per resident wave, allocated on the first
  *     solve of such a plan; up to round 3 more than 64 measurements were refused); the normal-equation kernel would pick other columns than SciPy on a rank-deficient basis, and
@@ -191,16 +218,20 @@ int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox, const f
  * 256-column product.  257 .. 512 bins run on SEPARATE, SLOWER instantiations (a "wide" plan): the Gram-form kernel with six
  * (up to 384 bins) or eight bins per lane and the 256 passive-set positions of the narrow kernel (twelve waves per CU, A^T y
  * on the vector unit, no block kernel, no MFMA step; a voxel whose passive set wants a 257th position is handed to a
- * 512-position instantiation), and the QR-form kernels with a wider dual.  Same algorithm, same decisions, same parity bar
- * (reference fixtures g11_*, oracle tests); measured on the C4 signal with 32 b-values: 3.4 M voxels/s at 300 bins, 2.7 M at
+ * 512-position instantiation), and the QR-form kernels with a wider dual.  Same algorithm and decisions on the reference
+ * fixtures g11_* and the oracle tests; NOT the same parity bar everywhere: a REGULARISED wide plan evaluates everything in Gram
+ * form (condition number squared; the narrow plans' residual-form dual does not exist at eight bins per lane), and on random
+ * ill-conditioned cases 2-3 % of them leave the oracle's path -- status flips at the iteration limit, coefficients off by up to
+ * 1.5e-4 of the peak against the narrow plans' 1e-6 (profiles/r04_v_fuzz_nnls_wide.json: 5 of 200 cases; the listed cases are
+ * the expected failures of `tests/fuzz_gpu_vs_oracle_nnls.py --wide`).  Measured on the C4 signal with 32 b-values: 3.4 M voxels/s at 300 bins, 2.7 M at
  * 384 and 1.7 M at 512 with the order-2 regulariser (8.6 M at 250: the step at 257 bins is a factor of 2.5), 8.8 M / 7.9 M
  * without (10.5 M at 250).
  * pnx_nnls_aty_f64 (the MFMA step on its own) stays a 256-column layout and refuses a wide plan.
  */
 typedef struct pnx_nnls_plan pnx_nnls_plan;
-int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
+PNX_API int pnx_nnls_plan_create(pnx_nnls_plan **plan, int n_meas, int n_bins, const double *basis, const double *reg,
                          int n_reg, int device);
-int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
+PNX_API int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
 
 /*
  * Batched NNLS  min ||A x - [y;0]||_2, x >= 0  per voxel, fp64, results matching scipy.optimize.nnls.
@@ -209,10 +240,10 @@ int pnx_nnls_plan_destroy(pnx_nnls_plan *plan);
  *   status (n_vox) int8, iters (n_vox) int32: out, may be NULL.  max_iter: reference's max_iter
  *   (0 -> 3*n_bins like SciPy).
  */
-int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
+PNX_API int pnx_nnls_solve_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, double *coeff,
                        double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
 /* fp32 storage of y, coeff and rnorm, fp64 arithmetic (halves the 8.4 GB coefficient volume of the C4 workload). */
-int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int max_iter, float *coeff, float *rnorm,
+PNX_API int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int max_iter, float *coeff, float *rnorm,
                        int8_t *status, int32_t *iters, int mem, void *stream);
 
 /*
@@ -221,10 +252,10 @@ int pnx_nnls_solve_f32(pnx_nnls_plan *plan, int64_t n_vox, const float *y, int m
  * This is the batched-GEMM part of what NNLSSolver._fit_single_pixel hands to scipy.optimize.nnls per voxel
  * (nnls_solver.py:195-197: A^T y of the normal equations); exposed so that it can be timed and checked by itself.
  */
-int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream);
+PNX_API int pnx_nnls_aty_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y_dev, double *aty_dev, void *stream);
 
 /* One-shot convenience: plan_create + solve + plan_destroy with host pointers. */
-int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
+PNX_API int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                        const double *y, int max_iter, double *coeff, double *rnorm, int8_t *status,
                        int32_t *iters, int device);
 
@@ -232,9 +263,9 @@ int pnx_nnls_batch_f64(int64_t n_vox, int n_meas, int n_bins, const double *basi
  * Design-matrix builders (model_functions/nnls.py:17-85), host in / host out, computed on the device
  * in fp64 so that a host language without numpy can build the same matrices.
  */
-int pnx_nnls_bins(double d_min, double d_max, int n_bins, double *bins);
-int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis, int device);
-int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg);
+PNX_API int pnx_nnls_bins(double d_min, double d_max, int n_bins, double *bins);
+PNX_API int pnx_nnls_basis(int n_meas, const double *b, int n_bins, const double *bins, double *basis, int device);
+PNX_API int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg);
 
 /*
  * NNLS spectrum post-processing on the device: what pyneapple.utility.spectrum does per voxel
@@ -252,7 +283,7 @@ int pnx_nnls_regularization_matrix(int n_bins, int order, double mu, double *reg
  *     its fractions would have to be normalised over peaks the table cannot hold; a 250-bin spectrum has at most 124 maxima);
  *   d_values / f_values (n_vox, max_peaks) NaN padded; d_cut / f_cut (n_vox, n_cut <= 8).  Outputs host|device as `mem`.
  */
-int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectrum, const double *bins_host, double height,
+PNX_API int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectrum, const double *bins_host, double height,
                                 int regularized, double rel_height, int max_peaks, int32_t *n_peaks, double *d_values,
                                 double *f_values, int n_cut, const double *cutoffs_host, double *d_cut, double *f_cut, int mem,
                                 int device, void *stream);
@@ -261,7 +292,7 @@ int pnx_nnls_spectrum_peaks_f64(int64_t n_vox, int n_bins, const double *spectru
  * 8.4 GB for a 256 x 256 x 64 volume); per voxel only the peak table, the cutoff table, rnorm / status / iters come back.
  * Arguments as pnx_nnls_solve_f64 and pnx_nnls_spectrum_peaks_f64; y and every output host|device as `mem`.
  */
-int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
+PNX_API int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y, int max_iter, const double *bins_host,
                              double height, int regularized, double rel_height, int max_peaks, int32_t *n_peaks,
                              double *d_values, double *f_values, int n_cut, const double *cutoffs_host, double *d_cut,
                              double *f_cut, double *rnorm, int8_t *status, int32_t *iters, int mem, void *stream);
@@ -270,7 +301,7 @@ int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y
  * out[linear_index[i], :] = (float) values[i, :] for the n_px fitted voxels (linear_index = C-order index into the
  * (X, Y, Z) grid).  values (n_px, k) float64, linear_index (n_px) int64, out float32: host|device as `mem`.
  */
-int pnx_scatter_maps_f32(const double *values, const int64_t *linear_index, int64_t n_px, int k, int64_t n_spatial, float *out,
+PNX_API int pnx_scatter_maps_f32(const double *values, const int64_t *linear_index, int64_t n_px, int k, int64_t n_spatial, float *out,
                          int mem, int device, void *stream);
 
 /*
@@ -284,9 +315,9 @@ int pnx_scatter_maps_f32(const double *values, const int64_t *linear_index, int6
  *   lower = clip(p0 (1 - tol), lo, hi), upper = clip(p0 (1 + tol), lo, hi)  (ideal.py:167-198).  Device pointers;
  *   lo / hi / tol (n_params,) on the host.
  */
-int pnx_resize2d_f64(const double *in, int X, int Y, int64_t C, double *out, int TX, int TY, int method, int mem,
+PNX_API int pnx_resize2d_f64(const double *in, int X, int Y, int64_t C, double *out, int TX, int TY, int method, int mem,
                      int device, void *stream);
-int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const double *lo_host, const double *hi_host,
+PNX_API int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const double *lo_host, const double *hi_host,
                          const double *tol_host, double *p0, double *lower, double *upper, int device, void *stream);
 
 /*
@@ -299,12 +330,12 @@ int pnx_ideal_bounds_f64(const double *map, int64_t n_px, int n_params, const do
  * pnx_row_ss_tot_f64: sum_j (y_ij - mean_i)^2 per row, the SS_tot of R^2 (fitters/base.py:179-183).
  * The last three only enqueue.
  */
-int pnx_mask_select_f64(const double *mask, int64_t n, double threshold, int64_t *idx, int64_t *n_selected, int device,
+PNX_API int pnx_mask_select_f64(const double *mask, int64_t n, double threshold, int64_t *idx, int64_t *n_selected, int device,
                         void *stream);
-int pnx_gather_rows_f64(const double *src, int64_t c, const int64_t *idx, int64_t n_sel, double *dst, int device, void *stream);
-int pnx_scatter_rows_t_f64(const double *popt, const int64_t *idx, int64_t n_sel, int k, int64_t n_total, double *pmap, int device,
+PNX_API int pnx_gather_rows_f64(const double *src, int64_t c, const int64_t *idx, int64_t n_sel, double *dst, int device, void *stream);
+PNX_API int pnx_scatter_rows_t_f64(const double *popt, const int64_t *idx, int64_t n_sel, int k, int64_t n_total, double *pmap, int device,
                            void *stream);
-int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int device, void *stream);
+PNX_API int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int device, void *stream);
 
 /*
  * Bulk copies between pageable host arrays and device buffers -- what torch's tensor.to(device) / tensor.cpu() (or a plain
@@ -314,8 +345,8 @@ int pnx_row_ss_tot_f64(const double *y, int64_t n, int c, double *out, int devic
  * download touches its destination pages first.  Both synchronise `stream` before they start and return when the bytes have
  * landed.
  */
-int pnx_upload(void *dst_device, const void *src_host, int64_t bytes, int device, void *stream, int threads);
-int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int device, void *stream, int threads);
+PNX_API int pnx_upload(void *dst_device, const void *src_host, int64_t bytes, int device, void *stream, int threads);
+PNX_API int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int device, void *stream, int threads);
 
 /*
  * Per-label column sums of an (n, c) row matrix and the rows per label: the reduction SegmentationWiseFitter performs with a
@@ -324,7 +355,7 @@ int pnx_download(void *dst_host, const void *src_device, int64_t bytes, int devi
  * sums (n_labels, c), counts (n_labels).  Deterministic (fixed summation order, no atomics).  mem: host pointers (the rows are
  * uploaded with pnx_upload's threaded copy) or device pointers; n_labels * (c + 1) <= 8192.  Synchronises the stream.
  */
-int pnx_label_sums_f64(const double *rows, const int32_t *labels, int64_t n, int c, int n_labels, double *sums, int64_t *counts,
+PNX_API int pnx_label_sums_f64(const double *rows, const int32_t *labels, int64_t n, int c, int n_labels, double *sums, int64_t *counts,
                        int mem, int device, void *stream);
 
 /*
@@ -334,9 +365,9 @@ int pnx_label_sums_f64(const double *rows, const int32_t *labels, int64_t n, int
  * Device pointers only.  T = float (f32) or double (f64).
  *   y (n_vox, n_b); params (n_all, n_vox); out_cost (n_vox); out_g (n_all, n_vox); out_jtj (n_tri, n_vox)
  */
-int pnx_sweep_f32(int model, int64_t n_vox, int n_b, const float *b_host, const float *y, const float *params,
+PNX_API int pnx_sweep_f32(int model, int64_t n_vox, int n_b, const float *b_host, const float *y, const float *params,
                   float *out_cost, float *out_g, float *out_jtj, int device, void *stream);
-int pnx_sweep_f64(int model, int64_t n_vox, int n_b, const double *b_host, const double *y, const double *params,
+PNX_API int pnx_sweep_f64(int model, int64_t n_vox, int n_b, const double *b_host, const double *y, const double *params,
                   double *out_cost, double *out_g, double *out_jtj, int device, void *stream);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ seeded synthetic inputs and stores inputs + outputs as small ``.npz`` fixtures
 under ``tests/golden/``.  Only data is written; no reference source travels.
 
 Run (from any cwd):  python3 oracle/gen_golden.py            (batches g1-g9)
-                     python3 oracle/gen_golden.py g10 | g11   (later batches, each with its own seed)
+                     python3 oracle/gen_golden.py g10 | g11 | g12   (later batches, each with its own seed)
 """
 from __future__ import annotations
 
@@ -67,7 +67,7 @@ def _noise(rng, clean, sigma):
 
 def gen_curvefit(name, model, names, truth_ranges, p0, bounds, nb, n_vox, sigmas, rng,
                  max_iter=250, tol=1e-8, bvalues=None, extra=None, per_voxel=False,
-                 fixed=None, scale=1.0):
+                 fixed=None, scale=1.0, solver_kwargs=None):
     from pyneapple import CurveFitSolver
 
     b = np.linspace(0.0, 1200.0, nb) if bvalues is None else np.asarray(bvalues, float)
@@ -85,10 +85,14 @@ def gen_curvefit(name, model, names, truth_ranges, p0, bounds, nb, n_vox, sigmas
         sig[idx] = s
     y = clean * (1.0 + sig[:, None] * rng.standard_normal(clean.shape))
 
-    solver = CurveFitSolver(model=model, max_iter=max_iter, tol=tol, p0=p0, bounds=bounds)
+    solver = CurveFitSolver(model=model, max_iter=max_iter, tol=tol, p0=p0, bounds=bounds, **(solver_kwargs or {}))
     kw = {}
     out = dict(bvalues=b, y=y, truth=truth, sigma=sig, max_iter=max_iter, tol=tol,
                param_names=np.array(model.param_names), all_param_names=np.array(all_names))
+    if solver_kwargs:  # what the reference forwards into scipy.optimize.curve_fit (solvers/curvefit.py:295-306): sigma, absolute_sigma
+        if solver_kwargs.get("sigma") is not None:
+            out["fit_sigma"] = np.atleast_1d(np.asarray(solver_kwargs["sigma"], float))
+        out["absolute_sigma"] = bool(solver_kwargs.get("absolute_sigma", False))
     free_names = list(model.param_names)
     if per_voxel:
         # IDEAL-style per-voxel p0 / bounds arrays (n_params, n_px); fitters/ideal.py:182-189
@@ -494,8 +498,48 @@ def main_g11():
             print(f"{name}: peaks/voxel mean {n_peaks.mean():.2f} max {n_peaks.max()}")
 
 
+def main_g12():
+    """Seventh batch (round 5): curve_fit(sigma=..., absolute_sigma=...) -- the two keyword arguments the reference's docstring
+    names and forwards (solvers/curvefit.py:33, 295-306): a 1-D sigma shared by the voxels (vector or scalar), with the
+    finite-difference Jacobian (no fixed parameter) and with the analytic one (a fixed parameter: _wrap_jac scales its rows)."""
+    from pyneapple import BiExpModel, TriExpModel
+
+    rng = np.random.default_rng(SEED + 12)
+    bi_p0 = {"f1": 0.2, "D1": 0.01, "D2": 0.001}
+    bi_bd = {"f1": (0.0, 1.0), "D1": (1e-3, 0.1), "D2": (1e-5, 5e-3)}
+    bi_tr = {"f1": (0.1, 0.4), "D1": (5e-3, 5e-2), "D2": (5e-4, 2e-3)}
+    tri_p0 = {"f1": 0.2, "D1": 0.05, "f2": 0.3, "D2": 0.005, "D3": 0.001}
+    tri_bd = {"f1": (0.0, 1.0), "D1": (0.01, 0.5), "f2": (0.0, 1.0), "D2": (2e-3, 0.01), "D3": (1e-5, 2e-3)}
+    tri_tr = {"f1": (0.1, 0.3), "D1": (0.03, 0.1), "f2": (0.2, 0.4), "D2": (3e-3, 8e-3), "D3": (5e-4, 1.5e-3)}
+    tri_names = ["f1", "D1", "f2", "D2", "D3"]
+    sig24 = 0.004 * (1.0 + np.linspace(0.0, 1200.0, 24) / 300.0)  # noise floor that grows with the b-value
+    sig32 = 0.004 * (1.0 + np.linspace(0.0, 1200.0, 32) / 300.0)
+    gen_curvefit("g12_bi_sigma_rel", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0, bi_bd, 24, 96, [0.0, 0.01, 0.03], rng,
+                 solver_kwargs=dict(sigma=sig24, absolute_sigma=False))
+    gen_curvefit("g12_bi_sigma_abs", BiExpModel(), ["f1", "D1", "D2"], bi_tr, bi_p0, bi_bd, 24, 96, [0.0, 0.01, 0.03], rng,
+                 solver_kwargs=dict(sigma=sig24, absolute_sigma=True))
+    gen_curvefit("g12_tri_sigma_abs", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 128, [0.0, 0.01, 0.03], rng,
+                 solver_kwargs=dict(sigma=sig32, absolute_sigma=True))
+    gen_curvefit("g12_tri_sigma_rel", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 128, [0.01, 0.03], rng,
+                 solver_kwargs=dict(sigma=sig32, absolute_sigma=False))
+    gen_curvefit("g12_tri_sigma_scalar", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 64, [0.01], rng,
+                 solver_kwargs=dict(sigma=0.05, absolute_sigma=True))
+    gen_curvefit("g12_tri_abs_nosigma", TriExpModel(), tri_names, tri_tr, tri_p0, tri_bd, 32, 64, [0.01], rng,
+                 solver_kwargs=dict(absolute_sigma=True))
+    gen_curvefit("g12_bi_s0_fixed_D1_sigma_abs", BiExpModel(fit_s0=True), ["f1", "D1", "D2", "S0"], dict(bi_tr, S0=(500, 1500)),
+                 dict(bi_p0, S0=1000.0), dict(bi_bd, S0=(1.0, 5000.0)), 24, 64, [0.0, 0.01], rng, fixed={"D1": (5e-3, 5e-2)},
+                 solver_kwargs=dict(sigma=4.0 * (1.0 + np.linspace(0.0, 1200.0, 24) / 300.0), absolute_sigma=True))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+        os.environ.setdefault("PYNEAPPLE_QUIET", "1")
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, REF_SRC)
+        _install_shims()
+        os.makedirs(OUT, exist_ok=True)
+        main_g12()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g7":  # only the second batch
         os.environ.setdefault("PYNEAPPLE_QUIET", "1")
         sys.dont_write_bytecode = True
         sys.path.insert(0, REF_SRC)

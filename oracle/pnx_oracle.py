@@ -51,6 +51,11 @@ def lib():
             C.c_int, C.c_int, C.c_double, C.c_double, C.c_long, C.c_int, dp, dp, C.c_int, ip, C.c_int, ip, dp, C.c_int,
             dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp,
             C.POINTER(C.c_int8), C.POINTER(C.c_int32), dp, C.c_int]
+        _lib.pnxo_curvefit_batch_sigma.restype = C.c_int
+        _lib.pnxo_curvefit_batch_sigma.argtypes = [
+            C.c_int, C.c_int, C.c_double, C.c_double, C.c_long, C.c_int, dp, dp, C.c_int, ip, C.c_int, ip, dp, C.c_int,
+            dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, dp, C.c_int, dp, dp,
+            C.POINTER(C.c_int8), C.POINTER(C.c_int32), dp, C.c_int]
         _lib.pnxo_nnls_batch.restype = C.c_int
         _lib.pnxo_nnls_batch.argtypes = [
             C.c_long, C.c_int, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp, dp,
@@ -63,10 +68,12 @@ def _dp(a):
 
 
 def curvefit(model: str, b, y, p0, lo, hi, *, t1_mode=0, tr=0.0, tm=0.0, fixed_idx=(), fixed_vals=None,
-             max_nfev=250, ftol=1e-8, xtol=1e-8, gtol=1e-8, jac="fd", want_pcov=True, n_threads=1):
+             max_nfev=250, ftol=1e-8, xtol=1e-8, gtol=1e-8, jac="fd", want_pcov=True, n_threads=1, sigma=None,
+             absolute_sigma=False):
     """Batched bounded NLLS (SciPy-TRF restatement).
 
     p0/lo/hi: (n_free,) shared or (n_free, n_vox) per voxel.  fixed_vals: (n_fixed,) or (n_fixed, n_vox).
+    sigma: None, a scalar or (n_b,) -- curve_fit's 1-D sigma, shared by the voxels; absolute_sigma as in curve_fit.
     Returns dict(popt (n_free,n_vox), pcov (n_vox,n_free,n_free), status int8, nfev int32, cost).
     """
     L = lib()
@@ -95,12 +102,14 @@ def curvefit(model: str, b, y, p0, lo, hi, *, t1_mode=0, tr=0.0, tm=0.0, fixed_i
     status = np.empty(n_vox, np.int8)
     nfev = np.empty(n_vox, np.int32)
     cost = np.empty(n_vox)
-    rc = L.pnxo_curvefit_batch(
+    if sigma is not None:
+        sigma = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, np.float64).reshape(-1), (n_b,)))
+    rc = L.pnxo_curvefit_batch_sigma(
         MODELS[model], t1_mode, tr, tm, n_vox, n_b, _dp(b), _dp(y), n_free,
         free_idx.ctypes.data_as(C.POINTER(C.c_int)), len(fixed_idx), fixed_idx.ctypes.data_as(C.POINTER(C.c_int)),
         _dp(fv), fpv, _dp(p0), _dp(lo), _dp(hi), per_voxel, max_nfev, ftol, xtol, gtol,
-        0 if jac == "fd" else 1, _dp(popt), _dp(pcov), status.ctypes.data_as(C.POINTER(C.c_int8)),
-        nfev.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost), n_threads)
+        0 if jac == "fd" else 1, _dp(sigma), int(bool(absolute_sigma)), _dp(popt), _dp(pcov),
+        status.ctypes.data_as(C.POINTER(C.c_int8)), nfev.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost), n_threads)
     if rc != 0:
         raise ValueError(f"pnxo_curvefit_batch rc={rc}")
     return dict(popt=popt, pcov=pcov, status=status, nfev=nfev, cost=cost)

@@ -56,6 +56,8 @@ typedef struct {
     const double *b;
     const double *y;
     double full[PNXO_MAXN]; /* full parameter vector; fixed slots pre-filled */
+    const double *w;        /* curve_fit(sigma=...): transform = 1 / sigma per measurement (scipy:_minpack_py.py:958-960), or NULL */
+    int absolute_sigma;     /* curve_fit(absolute_sigma=True): the covariance is not scaled by the reduced chi square */
 } prob_t;
 
 static int model_n_base(int model)
@@ -216,12 +218,15 @@ static void model_jacobian(const prob_t *P, const double *p, double *J)
     }
 }
 
-/* residual f = model(x) - y with free params x injected (models/base.py:145-165; _minpack_py.py:536-554) */
+/* residual f = model(x) - y with free params x injected (models/base.py:145-165; _minpack_py.py:536-554);
+ * with a 1-D sigma: transform * (model(x) - y) (_wrap_func, _minpack_py.py:545-547) */
 static void fun(prob_t *P, const double *x, double *f)
 {
     for (int k = 0; k < P->n_free; ++k) P->full[P->free_idx[k]] = x[k];
     model_forward(P, P->full, f);
     for (int i = 0; i < P->m; ++i) f[i] = f[i] - P->y[i];
+    if (P->w)
+        for (int i = 0; i < P->m; ++i) f[i] = P->w[i] * f[i];
 }
 
 static double vnorm(const double *v, int n)
@@ -686,6 +691,9 @@ static void jac_analytic(prob_t *P, const double *x, double *J)
     model_jacobian(P, P->full, Jall);
     for (int r = 0; r < m; ++r)
         for (int k = 0; k < n; ++k) J[r * n + k] = Jall[r * na + P->free_idx[k]];
+    if (P->w) /* _wrap_jac: transform[:, None] * jac (_minpack_py.py:560-562) */
+        for (int r = 0; r < m; ++r)
+            for (int k = 0; k < n; ++k) J[r * n + k] = P->w[r] * J[r * n + k];
 }
 
 static void compute_jac(prob_t *P, int jac_mode, const double *x, const double *f, const double *lb, const double *ub, double *J)
@@ -861,11 +869,14 @@ static int fit_one(prob_t *P, const double *p0, const double *lb, const double *
                 }
         } else
             bad = 1;
-        if (bad || !(m > n)) {
+        if (bad) {
             for (int i = 0; i < n * n; ++i) pcov[i] = INFINITY;
-        } else {
-            double s_sq = 2 * cost / (m - n);
-            for (int i = 0; i < n * n; ++i) pcov[i] = pcov[i] * s_sq;
+        } else if (!P->absolute_sigma) { /* _minpack_py.py:1057-1063 */
+            if (m > n) {
+                double s_sq = 2 * cost / (m - n);
+                for (int i = 0; i < n * n; ++i) pcov[i] = pcov[i] * s_sq;
+            } else
+                for (int i = 0; i < n * n; ++i) pcov[i] = INFINITY;
         }
     }
     return termination_status;
@@ -877,6 +888,13 @@ static int fit_one(prob_t *P, const double *p0, const double *lb, const double *
  *   fixed_vals (n_fixed,) shared or (n_fixed, n_vox); popt (n_free, n_vox); pcov (n_vox, n_free, n_free).
  * On failure (status <= 0) popt = p0 and pcov = NaN  (curvefit.py:308-317).
  */
+/* sigma: (n_b,) standard deviations of the measurements (curve_fit's 1-D sigma, shared by all voxels) or NULL */
+int pnxo_curvefit_batch_sigma(int model, int t1_mode, double tr, double tm, long n_vox, int n_b, const double *b,
+                              const double *y, int n_free, const int *free_idx, int n_fixed, const int *fixed_idx,
+                              const double *fixed_vals, int fixed_per_voxel, const double *p0, const double *lo,
+                              const double *hi, int per_voxel, int max_nfev, double ftol, double xtol, double gtol,
+                              int jac_mode, const double *sigma, int absolute_sigma, double *popt, double *pcov,
+                              int8_t *status, int32_t *nfev, double *cost, int n_threads);
 int pnxo_curvefit_batch(int model, int t1_mode, double tr, double tm, long n_vox, int n_b, const double *b,
                         const double *y, int n_free, const int *free_idx, int n_fixed, const int *fixed_idx,
                         const double *fixed_vals, int fixed_per_voxel, const double *p0, const double *lo,
@@ -884,6 +902,20 @@ int pnxo_curvefit_batch(int model, int t1_mode, double tr, double tm, long n_vox
                         int jac_mode, double *popt, double *pcov, int8_t *status, int32_t *nfev, double *cost,
                         int n_threads)
 {
+    return pnxo_curvefit_batch_sigma(model, t1_mode, tr, tm, n_vox, n_b, b, y, n_free, free_idx, n_fixed, fixed_idx, fixed_vals,
+                                     fixed_per_voxel, p0, lo, hi, per_voxel, max_nfev, ftol, xtol, gtol, jac_mode, NULL, 0, popt,
+                                     pcov, status, nfev, cost, n_threads);
+}
+int pnxo_curvefit_batch_sigma(int model, int t1_mode, double tr, double tm, long n_vox, int n_b, const double *b,
+                              const double *y, int n_free, const int *free_idx, int n_fixed, const int *fixed_idx,
+                              const double *fixed_vals, int fixed_per_voxel, const double *p0, const double *lo,
+                              const double *hi, int per_voxel, int max_nfev, double ftol, double xtol, double gtol,
+                              int jac_mode, const double *sigma, int absolute_sigma, double *popt, double *pcov,
+                              int8_t *status, int32_t *nfev, double *cost, int n_threads)
+{
+    double wbuf[PNXO_MAXM];
+    if (sigma && n_b >= 1 && n_b <= PNXO_MAXM)
+        for (int i = 0; i < n_b; ++i) wbuf[i] = 1.0 / sigma[i]; /* transform = 1.0 / sigma */
     const int n_all = pnxo_model_n_all(model, t1_mode);
     if (n_all < 0 || n_free < 1 || n_free > PNXO_MAXN || n_b < 1 || n_b > PNXO_MAXM) return -1;
     if (n_free + n_fixed != n_all) return -1;
@@ -903,6 +935,8 @@ int pnxo_curvefit_batch(int model, int t1_mode, double tr, double tm, long n_vox
         P.m = n_b;
         P.b = b;
         P.y = y + (size_t)vx * n_b;
+        P.w = sigma ? wbuf : NULL;
+        P.absolute_sigma = absolute_sigma;
         for (int k = 0; k < n_free; ++k) P.free_idx[k] = free_idx[k];
         for (int k = 0; k < n_fixed; ++k)
             P.full[fixed_idx[k]] = fixed_per_voxel ? fixed_vals[(size_t)k * n_vox + vx] : fixed_vals[k];

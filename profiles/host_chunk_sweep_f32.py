@@ -1,6 +1,7 @@
 """C3 through the float32 host entry point (pnx_curvefit_batch_f32, numpy float32 in and out) for a range of chunk sizes /
 slot counts of the host pipeline -- the float32 transfers are half as long as the float64 ones, so the chunk can grow (fewer
 persistent-kernel drain tails) at the same exposed transfer latency.  Prints PNX_HOST_TRACE timing lines when set."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -2,6 +2,7 @@
 """the plugin's n_gpus = N path from numpy arrays -- one host thread per device through the blocking
 ABI, each call with its upload / download / page-touch helpers -- rehearsed on one card (PNX_SHARE_DEVICE=1: every shard goes to
 device 0).  Prints the fit time, the peak number of threads of the process during the call and the helper budget in use."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

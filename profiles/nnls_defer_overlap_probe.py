@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """C4 from numpy arrays: the deferred hand-over pass behind the last chunk's solve on a stream of its own (overlapping that
 chunk's download) against the pass after the ring has drained (PNX_NNLS_DEFER_OVERLAP=0), alternating in one process."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

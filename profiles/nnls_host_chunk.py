@@ -1,6 +1,7 @@
 """C4 through the host entry point (numpy in, numpy (n_vox, 250) spectra out) for a range of host chunk sizes: every chunk is one
 launch of the block kernel plus one hand-over pass, so few large chunks beat many small ones until the last chunk's
 download (2 KB per voxel) is left exposed."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -2,6 +2,7 @@
 spends outside the ring (slot allocation, deferred hand-over pass, patching, frees), and whether the number of page-touch
 helpers matters (it does not: 649-656 ms with 1-4; the second full-size call of a process starts 10 ms late, later ones after
 2 ms; first launch to last kernel end is the resident 628 ms)."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

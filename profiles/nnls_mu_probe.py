@@ -4,6 +4,7 @@ Gram-form kernel when its passive set wants a 129th column, which costs that vox
 each (reg_order, mu): voxels/s of the block-kernel plan and of the Gram-form kernel alone (PNX_NNLS_NO_BLK=1), 2^18 voxels of
 the C4 signal, device resident, each in a fresh process.
     python profiles/nnls_mu_probe.py [order,mu ...]"""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import json, os, subprocess, sys
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''

@@ -1,4 +1,5 @@
 """C2 (biexp 128x128x32 x 24 b-values) from numpy arrays, call by call with the streamed path's trace."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

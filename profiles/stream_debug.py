@@ -1,4 +1,5 @@
 """Streamed host path vs chunk ring: where do they differ?  (debug aid for pnx_api.hip curvefit_streamed)"""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """SegmentedFitter's second step from numpy arrays: biexp with D1 fixed per voxel, 4 Mi voxels x 32 b-values, streamed host path
 against the chunk ring."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """Per-voxel start values and bounds from numpy arrays (what the reference's IDEAL fitter hands a solver plugin on its last
 level): triexp, 4 Mi voxels x 32 b-values, p0 / lo / hi each (5, n_vox); streamed host path against the chunk ring."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """C3 from numpy arrays (PCIe inclusive): streamed host path (one persistent kernel, pnx_api.hip curvefit_streamed) against
 the chunk ring, over granule sizes and upload piece sizes.  python profiles/stream_sweep.py [f32]"""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

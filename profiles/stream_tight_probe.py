@@ -2,6 +2,7 @@
 parameters) streamed with 8 / 64 / 200 of the 256 CUs left free for the runtime's copy kernels, the conversions and the epilogue
 (needed the knob PNX_STREAM_RESERVE_CUS of that build; profiles/r03_i_stream_tight_probe.txt: with 8 free CUs the upload sat
 behind the kernel until its poll limit, with 64 it ran).  The product keeps such fits on the chunk ring."""
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 import os, sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())
 import numpy as np

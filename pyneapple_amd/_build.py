@@ -18,7 +18,7 @@ OBJ = os.path.join(CSRC, "_obj" + ("_" + _VARIANT if _VARIANT else ""))
 LIB = os.path.join(HERE, f"libpnx_hip.{_VARIANT}.so" if _VARIANT else "libpnx_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+CXXFLAGS = [*os.environ.get("PNX_EXTRA_FLAGS", "").split(), "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 N_MODELS = 7
 # extra flags for the curve-fit translation units only (experiments: PNX_CURVEFIT_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp")
 CURVEFIT_FLAGS = os.environ.get("PNX_CURVEFIT_FLAGS", "").split()
@@ -131,7 +131,16 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
                 sys.stderr.write(f"[pnx build] {obj}: rc={rc}\n{out}\n")
             if rc:
                 raise RuntimeError(f"hipcc failed for {obj}")
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    # the dynamic symbol table is the header's function list and nothing else: a linker version script made from include/pnx.h
+    # (-fvisibility=hidden alone leaves the C++ runtime's template instantiations and the kernels' host-side handles visible)
+    import re
+
+    with open(os.path.join(HERE, "..", "include", "pnx.h")) as fh:
+        api = sorted(set(re.findall(r"^PNX_API\s+int\s+(pnx_[a-z0-9_]+)\s*\(", fh.read(), flags=re.M)))
+    vscript = os.path.join(OBJ, "pnx_exports.map")
+    with open(vscript, "w") as fh:
+        fh.write("{\n  global:\n" + "".join(f"    {n};\n" for n in api) + "  local:\n    *;\n};\n")
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={vscript}", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         sys.stderr.write(r.stdout + r.stderr)

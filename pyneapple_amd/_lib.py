@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pnx_nnls_bins", "pnx_nnls_basis", "pnx_nnls_regularization_matrix", "pnx_sweep_f32", "pnx_sweep_f64",
     "pnx_resize2d_f64", "pnx_ideal_bounds_f64", "pnx_nnls_spectrum_peaks_f64", "pnx_nnls_solve_peaks_f64", "pnx_scatter_maps_f32",
     "pnx_mask_select_f64", "pnx_gather_rows_f64", "pnx_scatter_rows_t_f64", "pnx_row_ss_tot_f64", "pnx_upload", "pnx_download",
-    "pnx_label_sums_f64", "pnx_release_staging", "pnx_curvefit_queue_order", "pnx_queue_order_f64",
+    "pnx_label_sums_f64", "pnx_release_staging", "pnx_queue_order_f64",
 ]
 
 
@@ -42,8 +42,10 @@ class CurvefitOpts(C.Structure):
         ("model", C.c_int32), ("n_b", C.c_int32), ("n_free", C.c_int32), ("n_fixed", C.c_int32),
         ("free_idx", C.c_int32 * PNX_MAX_PARAMS), ("fixed_idx", C.c_int32 * PNX_MAX_PARAMS),
         ("per_voxel_p0_bounds", C.c_int32), ("fixed_per_voxel", C.c_int32), ("max_nfev", C.c_int32),
-        ("jac_mode", C.c_int32), ("t1_mode", C.c_int32), ("reserved0", C.c_int32), ("tr", C.c_double),
+        ("jac_mode", C.c_int32), ("t1_mode", C.c_int32), ("absolute_sigma", C.c_int32), ("tr", C.c_double),
         ("tm", C.c_double), ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
+        ("sigma", C.c_void_p),        # (n_b,) float64 on the host, or None
+        ("queue_order", C.c_void_p),  # (n_vox,) int32 on the device, or None (device-mode calls only)
     ]
 
 
@@ -92,8 +94,6 @@ def load():
     vp, dp, fp = C.c_void_p, C.c_void_p, C.c_void_p
     lib.pnx_version.restype = C.c_int
     lib.pnx_release_staging.argtypes = [C.c_int]
-    lib.pnx_curvefit_queue_order.argtypes = [C.c_void_p]
-    lib.pnx_curvefit_queue_order.restype = C.c_int
     lib.pnx_queue_order_f64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
     lib.pnx_queue_order_f64.restype = C.c_int
     lib.pnx_release_staging.restype = C.c_int

@@ -25,7 +25,9 @@ def _is_torch(a):
 
 
 def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, max_nfev=250, ftol=1e-8, xtol=1e-8,
-              gtol=1e-8, jac="fd", t1_mode=0, tr=0.0, tm=0.0):
+              gtol=1e-8, jac="fd", t1_mode=0, tr=0.0, tm=0.0, sigma=None, absolute_sigma=False):
+    """pnx_curvefit_opts.  sigma: None, a scalar or (n_b,) -- curve_fit's 1-D sigma shared by all voxels (a 2-D sigma is
+    refused as SciPy refuses a wrong shape); absolute_sigma as in curve_fit.  The struct keeps the sigma array alive."""
     n_all = len(MODEL_PARAM_NAMES[model]) + (1 if t1_mode else 0)
     fixed_idx = [int(i) for i in fixed_idx]
     free_idx = [i for i in range(n_all) if i not in fixed_idx]
@@ -44,6 +46,16 @@ def make_opts(model, n_b, fixed_idx=(), per_voxel=False, fixed_per_voxel=False, 
     o.jac_mode = JAC_FD if jac == "fd" else JAC_ANALYTIC
     o.t1_mode, o.tr, o.tm = int(t1_mode), float(tr), float(tm)
     o.ftol, o.xtol, o.gtol = float(ftol), float(xtol), float(gtol)
+    o.absolute_sigma = int(bool(absolute_sigma))
+    if sigma is not None:
+        sg = np.asarray(sigma, np.float64)
+        if sg.size == 1:
+            sg = np.full(int(n_b), float(sg.reshape(-1)[0]))
+        elif sg.shape != (int(n_b),):
+            raise ValueError("`sigma` has incorrect shape." if sg.ndim != 2 else
+                             "a 2-D sigma (covariance matrix of the measurements) is not implemented by the HIP solver")
+        o._sigma_keepalive = np.ascontiguousarray(sg)  # the struct holds a raw pointer
+        o.sigma = o._sigma_keepalive.ctypes.data
     return o
 
 
@@ -59,7 +71,8 @@ def _out(out, key, shape, dtype):
 
 
 def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev=250, ftol=1e-8, xtol=1e-8,
-             gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0, out=None):
+             gtol=1e-8, jac="fd", want_pcov=True, device=0, t1_mode=0, tr=0.0, tm=0.0, out=None, sigma=None,
+             absolute_sigma=False):
     """Batched bounded NLLS on host (numpy) arrays.  Shapes as in include/pnx.h.
 
     A float32 signal array selects the fp32-storage entry point (pnx_curvefit_batch_f32: every data array float32 in
@@ -83,7 +96,7 @@ def curvefit(model, b, y, p0, lo, hi, *, fixed_idx=(), fixed_vals=None, max_nfev
     if len(fixed_idx):
         fv = np.ascontiguousarray(fixed_vals, dt)
         fpv = fv.ndim == 2
-    o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac, t1_mode, tr, tm)
+    o = make_opts(model, n_b, fixed_idx, per_voxel, fpv, max_nfev, ftol, xtol, gtol, jac, t1_mode, tr, tm, sigma, absolute_sigma)
     n = o.n_free
     want = (n, n_vox) if per_voxel else (n,)
     if p0.shape != want or lo.shape != want or hi.shape != want:
@@ -117,13 +130,14 @@ def curvefit_device(opts, n_vox, b, y, p0, lo, hi, fixed, popt, pcov, status, nf
     if isinstance(fixed, np.ndarray):
         fixed = np.ascontiguousarray(fixed, b.dtype)
     fn = load().pnx_curvefit_batch_f32 if f32 else load().pnx_curvefit_batch_f64
-    if order is not None:
-        if tuple(order.shape) != (int(n_vox),) or "int32" not in str(order.dtype):
-            raise ValueError("order must be an int32 device tensor of n_vox entries")
-        check(load().pnx_curvefit_queue_order(ptr(order)))
-    check(fn(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
-                                        ptr(fixed), ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost),
-                                        MEM_DEVICE, int(device), stream))
+    if order is not None and (tuple(order.shape) != (int(n_vox),) or "int32" not in str(order.dtype)):
+        raise ValueError("order must be an int32 device tensor of n_vox entries")
+    opts.queue_order = ptr(order)  # explicit per call (None clears what an earlier call with these opts set)
+    try:
+        check(fn(C.byref(opts), int(n_vox), ptr(b), ptr(y), ptr(p0), ptr(lo), ptr(hi),
+                 ptr(fixed), ptr(popt), ptr(pcov), ptr(status), ptr(nfev), ptr(cost), MEM_DEVICE, int(device), stream))
+    finally:
+        opts.queue_order = None
 
 
 class NnlsPlan:

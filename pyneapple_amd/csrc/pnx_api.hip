@@ -116,7 +116,7 @@ typedef PipeOpsT<hipStream_t> PipeOps;
 
 static int run_pipeline(int n_chunks, int n_slots, int k_streams, int touchers, int device, hipStream_t user_stream,
                         const PipeOps &ops) {
-    return run_pipeline_t<HipBackend>(n_chunks, n_slots, k_streams, touchers, device, user_stream, ops, getenv("PNX_HOST_TRACE") != nullptr);
+    return run_pipeline_t<HipBackend>(n_chunks, n_slots, k_streams, touchers, device, user_stream, ops, dev_getenv("PNX_HOST_TRACE") != nullptr);
 }
 
 // write one byte per page of [p, p + bytes): first-touch faults taken here, in parallel with the running kernel,
@@ -130,12 +130,21 @@ static void touch_pages(void *p, size_t bytes) {
     for (size_t off = (4096 - (a & 4095)) & 4095; off < bytes; off += 4096) c[off] = 0;
 }
 
-static int env_int(const char *name, int dflt, int lo, int hi) {
+// the environment helpers are shared by the translation units (pnx_internal.hpp)
+int env_int(const char *name, int dflt, int lo, int hi) {
     const char *e = getenv(name);
     if (!e) return dflt;
     const long v = atol(e);
     return v < lo ? lo : (v > hi ? hi : (int)v);
 }
+const char *dev_getenv(const char *name) {
+    static const bool enabled = [] {
+        const char *e = getenv("PNX_ENABLE_TEST_HOOKS");
+        return e && e[0] == '1' && e[1] == 0;
+    }();
+    return enabled ? getenv(name) : nullptr;
+}
+int dev_env_int(const char *name, int dflt, int lo, int hi) { return dev_getenv(name) ? env_int(name, dflt, lo, hi) : dflt; }
 
 // Helper threads of a host-array call.  One call uses an upload thread, one or two download threads and two page-touch
 // helpers; the plugin's n_gpus = N (one call per device at once) and callers with several volumes in flight multiply that,
@@ -188,13 +197,10 @@ struct StreamLaunch {
     int phase = 0;
 };
 
-// pnx_curvefit_queue_order: the calling thread's NEXT device-mode fit pulls its voxels in this order
-static thread_local const int32_t *g_next_order = nullptr;
-
 static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const double *b, const double *y_d,
                            const double *p0, const double *lo, const double *hi, const double *fixed, double *popt_d,
                            double *pcov_d, int8_t *status_d, int32_t *nfev_d, double *cost_d, DeviceInfo *dev,
-                           hipStream_t stream, const StreamLaunch *sl = nullptr) {
+                           hipStream_t stream, const StreamLaunch *sl = nullptr, const int32_t *order = nullptr) {
     CurvefitArgs a;
     memset(&a, 0, sizeof(a));
     if (sl) {
@@ -204,10 +210,7 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
         a.stream_spins = sl->spins;
         a.phase = sl->phase;
     }
-    if (!sl) {
-        a.order = g_next_order;
-        g_next_order = nullptr;
-    }
+    a.order = sl ? nullptr : order;  // device-mode calls only (pnx_curvefit_opts::queue_order): a streamed launch completes its granules in index order
     a.y = y_d;
     a.popt = popt_d;
     a.pcov = pcov_d;
@@ -229,6 +232,10 @@ static int curvefit_device(const pnx_curvefit_opts *o, int64_t n_vox, const doub
     for (int k = 0; k < o->n_free; ++k) a.free_idx[k] = o->free_idx[k];
     for (int k = 0; k < o->n_fixed; ++k) a.fixed_idx[k] = o->fixed_idx[k];
     for (int i = 0; i < o->n_b; ++i) a.b[i] = b[i];
+    a.absolute_sigma = o->absolute_sigma != 0;
+    a.use_sigma = o->sigma != nullptr;
+    if (o->sigma)
+        for (int i = 0; i < o->n_b; ++i) a.w[i] = 1.0 / o->sigma[i];  // transform = 1.0 / sigma (a zero sigma gives the reference's "Residuals are not finite" failure)
     if (o->per_voxel_p0_bounds) {
         a.p0 = p0;
         a.lo = lo;
@@ -470,10 +477,10 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     // voxels per upload / watermark step.  Per-voxel p0 / bounds ride along as 3 n row slices per piece: at 128 Ki voxels those
     // are 1 MB copies and the upload (1.57 GB for C3) runs at 36 GB/s and holds the kernel back (53-58 ms, the ring's 55); at
     // 512 Ki 47-50 ms (profiles/stream_pv_probe.py)
-    const size_t in_piece = (size_t)env_int("PNX_STREAM_IN_CHUNK", p0_pv ? 1 << 19 : 1 << 17, 1024, 1 << 26);
+    const size_t in_piece = (size_t)dev_env_int("PNX_STREAM_IN_CHUNK", p0_pv ? 1 << 19 : 1 << 17, 1024, 1 << 26);
     const int n_in = (int)((nv + in_piece - 1) / in_piece);
     const bool need_stat = status || pcov, need_cost = cost || pcov;
-    const bool trace = getenv("PNX_HOST_TRACE") != nullptr;
+    const bool trace = dev_getenv("PNX_HOST_TRACE") != nullptr;
     const auto t_call = std::chrono::steady_clock::now();
     auto now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     if (user_stream) PNX_HIP(hipStreamSynchronize(user_stream));
@@ -533,7 +540,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     sl.ctl = ctl;
     sl.host_flags = flags_dev;
     sl.granule_shift = gshift;
-    sl.spins = (unsigned int)env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 20);  // ~6 us per poll: 2.4 s, at most ~6 s (the host's own
+    sl.spins = (unsigned int)dev_env_int("PNX_STREAM_SPINS", 400000, 1000, 1 << 20);  // ~6 us per poll: 2.4 s, at most ~6 s (the host's own
                                                                                    // watchdog below gives up after PNX_STREAM_STALL_MS)
     sl.phase = 1;
     rc = curvefit_device(o, (int64_t)nv, bd, dy, pv ? dp0 : p0d, pv ? dlo : lod, pv ? dhi : hid, n_fpv ? dfx : fxd, dpopt, dpcov, dstat,
@@ -636,10 +643,10 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
     };
     // a watermark that has not moved this long after the launch will not move: the first piece lands after 0.7 ms (C3), a
     // 512 Ki-voxel piece with per-voxel arrays after 3-4 ms
-    const double stall_ms = env_int("PNX_STREAM_STALL_MS", 50, 1, 60000);
+    const double stall_ms = dev_env_int("PNX_STREAM_STALL_MS", 50, 1, 60000);
     bool stalled = false;
     StreamedTimes times;
-    rc = run_streamed(n_in, n_gran, n_out, hg.touchers(), stall_ms, env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000),
+    rc = run_streamed(n_in, n_gran, n_out, hg.touchers(), stall_ms, dev_env_int("PNX_STREAM_TEST_DELAY_MS", 0, 0, 60000),
                       ops, &stalled, trace ? &times : nullptr, now);
     (void)hipStreamSynchronize(s_in);  // nothing of this call is left on the kept streams
     (void)hipEventDestroy(ev_first);
@@ -654,7 +661,7 @@ static int curvefit_streamed(const pnx_curvefit_opts *o, size_t nv, const double
             fprintf(stderr, "[pnx stream] granule %d complete at %.2f, downloaded by %.2f ms\n", g, times.t_flag[g], times.t_out[g]);
     }
     if (stalled || head.timed_out) {
-        g_stream_cooldown[device].store(env_int("PNX_STREAM_COOLDOWN", 32, 0, 1 << 20));
+        g_stream_cooldown[device].store(dev_env_int("PNX_STREAM_COOLDOWN", 32, 0, 1 << 20));
         return kStreamRetry;
     }
     return PNX_OK;
@@ -673,6 +680,8 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
     if (!b || !p0 || !lo || !hi || !popt || (n_vox && !y)) return set_error(PNX_ERR_INVALID, "NULL data pointer");
     if (o->n_fixed && !fixed) return set_error(PNX_ERR_INVALID, "fixed is NULL but n_fixed=%d", o->n_fixed);
     if (mem != PNX_MEM_HOST && mem != PNX_MEM_DEVICE) return set_error(PNX_ERR_INVALID, "mem=%d", mem);
+    if (o->queue_order && mem != PNX_MEM_DEVICE)
+        return set_error(PNX_ERR_INVALID, "opts->queue_order is for PNX_MEM_DEVICE calls (a host-array call completes its pieces in index order)");
     if (n_vox == 0) return PNX_OK;
     DeviceInfo *dev;
     rc = get_device(device, &dev);
@@ -701,7 +710,8 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         hipStream_t st = (hipStream_t)stream;
         if constexpr (!F32) {
             return curvefit_device(o, n_vox, bd, as_d(y), pv ? as_d(p0) : p0d, pv ? as_d(lo) : lod, pv ? as_d(hi) : hid,
-                                   fpv ? as_d(fixed) : fxd, (double *)popt, (double *)pcov, status, nfev, (double *)cost, dev, st);
+                                   fpv ? as_d(fixed) : fxd, (double *)popt, (double *)pcov, status, nfev, (double *)cost, dev, st, nullptr,
+                                   o->queue_order);
         } else {
             AsyncBuf y64, p64, l64, h64, f64, o64, c64, k64;
             if ((rc = y64.alloc(nv * o->n_b * 8, st)) || (rc = cvt(y, (double *)y64.p, nv * o->n_b, st))) return rc;
@@ -718,7 +728,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
             rc = curvefit_device(o, n_vox, bd, (const double *)y64.p, pv ? (const double *)p64.p : p0d,
                                  pv ? (const double *)l64.p : lod, pv ? (const double *)h64.p : hid,
                                  fpv ? (const double *)f64.p : fxd, (double *)o64.p, pcov ? (double *)c64.p : nullptr, status,
-                                 nfev, (double *)k64.p, dev, st);
+                                 nfev, (double *)k64.p, dev, st, nullptr, o->queue_order);
             if (rc) return rc;
             if ((rc = cvt((const double *)o64.p, popt, nv * n, st))) return rc;
             if (pcov && (rc = cvt((const double *)c64.p, pcov, nv * n * n, st))) return rc;
@@ -732,9 +742,9 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
     {
         // granule = unit of the download (and of the completion flags): 256 Ki voxels for volumes of 2 Mi voxels and more,
         // 128 Ki below (C3: 2^17 41.4-44 ms, 2^18 40.6-43.9 ms, 2^16 and 2^19 42-45 ms; profiles/stream_sweep.py)
-        const int gshift = env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
+        const int gshift = dev_env_int("PNX_STREAM_GRANULE_SHIFT", nv >= ((size_t)1 << 21) ? 18 : 17, 10, 24);
         const size_t per_vox = (size_t)(o->n_b + n + (pcov ? n * n : 0) + 2 + (fpv ? o->n_fixed : 0) + (pv ? 3 * n : 0)) * (F32 ? 12 : 8);
-        size_t max_bytes = (size_t)env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
+        size_t max_bytes = (size_t)dev_env_int("PNX_STREAM_MAX_MB", 65536, 1, 1 << 20) << 20;
         {   // never more than half of what is free now (plus the kept slab, which would be reused): a volume beyond that goes
             // through the ring's three chunk slots instead of one huge hipMalloc that fails or starves the process
             size_t free_b = 0, total_b = 0;
@@ -755,13 +765,13 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
             g_stream_cooldown[device].fetch_sub(1);
             cooling = true;
         }
-        if (!cooling && env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
+        if (!cooling && dev_env_int("PNX_HOST_STREAM", 1, 0, 1) && !(pv && o->n_fixed) && !tight && nv > ((size_t)1 << gshift) &&
             nv < ((size_t)1 << 31) && nv * per_vox <= max_bytes) {
             rc = curvefit_streamed<T>(o, nv, bd, y, p0d, lod, hid, pv ? p0 : nullptr, pv ? lo : nullptr, pv ? hi : nullptr, fxd,
                                       fpv ? fixed : nullptr, popt, pcov, status, nfev, cost, gshift, dev, device, (hipStream_t)stream, hg);
             if (rc != kStreamRetry) return rc;
             static std::atomic<bool> warned(false);
-            if (getenv("PNX_HOST_TRACE") || !warned.exchange(true))
+            if (dev_getenv("PNX_HOST_TRACE") || !warned.exchange(true))
                 fprintf(stderr, "[pnx stream] the streamed launch could not be used (no room for the staging slab, or its upload did not "
                                 "start within PNX_STREAM_STALL_MS); running the call through the chunk ring, and after a stall the next "
                                 "PNX_STREAM_COOLDOWN calls of this device too. PNX_HOST_STREAM=0 skips the attempt.\n");
@@ -771,12 +781,12 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
     // ---- host staging: chunk ring (run_pipeline above)
     // float32 transfers are half as long per voxel: a larger chunk (fewer drain tails of the persistent kernel) at the same
     // exposed transfer latency -- C3 float32: 86.3 M voxels/s at 768 Ki, 89.8 M at 1 Mi, 82.5 M at 2 Mi (profiles/host_chunk_sweep_f32.py)
-    const size_t chunk = (size_t)env_int("PNX_HOST_CHUNK", F32 ? 1 << 20 : 3 << 18, 1024, 1 << 26);
+    const size_t chunk = (size_t)dev_env_int("PNX_HOST_CHUNK", F32 ? 1 << 20 : 3 << 18, 1024, 1 << 26);
     // chunk boundaries: with three or more full chunks the first and the last piece are a quarter chunk -- the first kernel
     // starts after a quarter of an upload, and the serial tail (last kernel, last download) is a quarter as long
     std::vector<size_t> bounds;
     {
-        const size_t ramp = env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk ? chunk / 4 : 0;
+        const size_t ramp = dev_env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk ? chunk / 4 : 0;
         size_t v = 0;
         bounds.push_back(0);
         if (ramp) bounds.push_back(v = ramp);
@@ -785,7 +795,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         if (ramp) bounds.push_back(nv);
     }
     const int n_chunks = (int)bounds.size() - 1;
-    const int n_slots = n_chunks < 3 ? n_chunks : env_int("PNX_HOST_SLOTS", 3, 2, 8);
+    const int n_slots = n_chunks < 3 ? n_chunks : dev_env_int("PNX_HOST_SLOTS", 3, 2, 8);
     const size_t cap = nv < chunk ? nv : chunk;
     const bool need_stat = status || pcov, need_cost = cost || pcov;
     struct Slot {
@@ -887,7 +897,7 @@ static int curvefit_batch(const pnx_curvefit_opts *o, int64_t n_vox, const T *b,
         if (cost) PNX_HIP(hipMemcpyAsync(cost + v0, S.tcost, c * sizeof(T), hipMemcpyDeviceToHost, st));
         return PNX_OK;
     };
-    return run_pipeline(n_chunks, n_slots, env_int("PNX_HOST_KSTREAMS", 2, 1, 4), hg.touchers(), device, (hipStream_t)stream, ops);
+    return run_pipeline(n_chunks, n_slots, dev_env_int("PNX_HOST_KSTREAMS", 2, 1, 4), hg.touchers(), device, (hipStream_t)stream, ops);
 }
 
 extern "C" {
@@ -903,11 +913,8 @@ int pnx_release_staging(int device) {
         g_sres[device].release();
         (void)hipSetDevice(cur);
     }
-    return PNX_OK;
-}
-
-int pnx_curvefit_queue_order(const int32_t *order_device) {
-    g_next_order = order_device;
+    // the slab set the block-kernel NNLS plans of this device share (pnx_nnls.hpp): freed when no plan holds it, kept otherwise
+    (void)nnls_shared_slabs_trim(device);
     return PNX_OK;
 }
 
@@ -1005,13 +1012,13 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     // every chunk is one launch of the solver plus (block kernel) one hand-over pass of ~8 ms: C4 from numpy arrays takes
     // 759 / 712 / 682 / 698 ms with chunks of 256 Ki / 512 Ki / 768 Ki / 1 Mi voxels (profiles/nnls_host_chunk.py) -- beyond
     // 768 Ki the last chunk's download (2 KB per voxel) is what grows
-    const size_t chunk = (size_t)env_int("PNX_NNLS_HOST_CHUNK", 3 << 18, 1024, 1 << 22);
+    const size_t chunk = (size_t)dev_env_int("PNX_NNLS_HOST_CHUNK", 3 << 18, 1024, 1 << 22);
     // chunk boundaries.  Block-kernel plans with three or more chunks (their hand-over pass is deferred, see below, so a
     // chunk more costs ~1.5 ms, not 8): the first and the last piece are a quarter chunk -- the first launch starts after a
     // quarter of an upload, and the download left exposed at the end is 0.4 GB instead of 1.6 (2 KB per voxel).
     std::vector<size_t> bounds;
     {
-        const size_t ramp = (P.blk && env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk) ? chunk / 4 : 0;
+        const size_t ramp = (P.blk && dev_env_int("PNX_HOST_RAMP", 1, 0, 1) && nv >= 3 * chunk) ? chunk / 4 : 0;
         size_t v = 0;
         bounds.push_back(0);
         if (ramp) bounds.push_back(v = ramp);
@@ -1051,7 +1058,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
     // number (they are the longest solves there are): with several chunks the hand-over is deferred -- the chunks only
     // collect the voxels' indices and signal rows, ONE pass at the end of the call solves them, and their rows are patched
     // into the caller's arrays (C4 from numpy arrays: seven passes -> one).
-    const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
+    const int defer_cap = dev_env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
     const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
     DevBuf dslab;
     NnlsDefer dctx{};
@@ -1094,7 +1101,7 @@ static int nnls_solve(pnx_nnls_plan *plan, int64_t n_vox, const T *y, int max_it
         }
         PNX_HIP(hipEventCreateWithFlags(&side.e, hipEventDisableTiming));
     }
-    const bool overlap_pass = env_int("PNX_NNLS_DEFER_OVERLAP", 1, 0, 1) != 0;
+    const bool overlap_pass = dev_env_int("PNX_NNLS_DEFER_OVERLAP", 1, 0, 1) != 0;
     auto run = [&](const bool defer) -> int {
         if (defer) PNX_HIP(hipMemset(dctx.counters, 0, 2 * sizeof(int32_t)));
         auto span = [&](int k, size_t &off, size_t &c) {
@@ -1231,7 +1238,7 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
     if (max_peaks > 0 && (!d_values || !f_values)) return set_error(PNX_ERR_INVALID, "d_values / f_values are NULL");
     if (n_cut > 0 && (!cutoffs_host || !d_cut || !f_cut)) return set_error(PNX_ERR_INVALID, "cutoffs / d_cut / f_cut are NULL");
     const size_t nv = (size_t)n_vox;
-    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 3 << 18, 1024, 1 << 22);
+    const size_t chunk = (size_t)dev_env_int("PNX_NNLS_PEAKS_CHUNK", 3 << 18, 1024, 1 << 22);
     const int n_chunks = (int)((nv + chunk - 1) / chunk);
     const int n_slots = n_chunks < 3 ? n_chunks : 3;
     const size_t cap = nv < chunk ? nv : chunk;
@@ -1271,7 +1278,7 @@ static int nnls_solve_peaks_host(pnx_nnls_plan *plan, int64_t n_vox, const doubl
         return pnx_nnls_spectrum_peaks_f64((int64_t)n, P.n_bins, o.spec, bins_host, height, regularized, rel_height, max_peaks, o.np, o.d,
                                            o.f, n_cut, cutoffs_host, o.dc, o.fc, PNX_MEM_DEVICE, P.device, s);
     };
-    const int defer_cap = env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
+    const int defer_cap = dev_env_int("PNX_NNLS_DEFER_CAP", 16384, 0, 1 << 22);
     const bool can_defer = P.blk && n_chunks >= 2 && defer_cap > 0 && nv < ((size_t)1 << 31);
     DevBuf dslab;
     NnlsDefer dctx{};
@@ -1433,11 +1440,11 @@ int pnx_nnls_solve_peaks_f64(pnx_nnls_plan *plan, int64_t n_vox, const double *y
     hipStream_t st = (hipStream_t)stream;
     if (max_iter <= 0) max_iter = 3 * P.n_bins;
     std::lock_guard<std::mutex> plan_lock(plan->mu);
-    if (mem == PNX_MEM_HOST && env_int("PNX_NNLS_PEAKS_RING", 1, 0, 1))
+    if (mem == PNX_MEM_HOST && dev_env_int("PNX_NNLS_PEAKS_RING", 1, 0, 1))
         return nnls_solve_peaks_host(plan, n_vox, y, max_iter, bins_host, height, regularized, rel_height, max_peaks, n_peaks, d_values,
                                      f_values, n_cut, cutoffs_host, d_cut, f_cut, rnorm, status, iters, st);
     // spectra of one chunk live in device scratch only: solve -> peak analysis -> next chunk
-    const size_t chunk = (size_t)env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 20, 1024, 1 << 22);
+    const size_t chunk = (size_t)dev_env_int("PNX_NNLS_PEAKS_CHUNK", 1 << 20, 1024, 1 << 22);
     const size_t nv = (size_t)n_vox, cap = nv < chunk ? nv : chunk;
     DevBuf spec, stage;
     int rc;

@@ -12,7 +12,7 @@ namespace pnx {
 template <int N> static int launch_pcov(const CurvefitArgs &args, const ColPerm &cp, hipStream_t stream) {
     const int pb = 256;
     hipLaunchKernelGGL(pcov_kernel<N>, dim3((unsigned)((args.n_vox + pb - 1) / pb)), dim3(pb), 0, stream, args.pcov,
-                       (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp);
+                       (const int8_t *)args.status, (const double *)args.cost, args.n_vox, args.n_b, cp, args.absolute_sigma);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(PNX_ERR_HIP, "pcov launch: %s", hipGetErrorString(e));
     return PNX_OK;
@@ -28,7 +28,7 @@ static int launch_one(const CurvefitArgs &args, int device_cus, hipStream_t stre
     // LDS per block: b-value table + per wave: [n_b][64] signal tile, parked R factor and singular vectors.
     // Up to 4 waves per block; fewer when that would not fit 160 KiB.
     int waves = PNX_CF_BLOCK_WAVES;
-    auto bytes = [&](int w) { return sizeof(double) * (kMaxB + (size_t)w * Park<N>::per_wave(args.n_b)); };
+    auto bytes = [&](int w) { return sizeof(double) * ((args.use_sigma ? 2 * kMaxB : kMaxB) + (size_t)w * Park<N>::per_wave(args.n_b)); };  // + the 1 / sigma table
     while (waves > 1 && bytes(waves) > 160 * 1024) --waves;
     if (bytes(waves) > 160 * 1024) return set_error(PNX_ERR_UNSUPPORTED, "n_b=%d does not fit the LDS tile", args.n_b);
     const int block = waves * kWave;

@@ -64,7 +64,7 @@ struct CurvefitArgs {
     double *cost;
     unsigned long long *queue;  // work-queue head, zeroed before launch
     const int32_t *order;       // null, or (n_vox) a permutation: the queue's k-th pull fits voxel order[k] (longest fits first, see
-                                // pnx_curvefit_queue_order); never with a streamed launch (granules complete in index order)
+                                // pnx_curvefit_opts::queue_order); never with a streamed launch (granules complete in index order)
     // Streamed launch (host-pointer calls, pnx_api.hip `curvefit_streamed`): ONE persistent kernel runs while the volume is
     // still being uploaded and its results are already being downloaded.  ctl != null selects the STREAM instantiation.
     StreamCtl *ctl;             // device memory: upload watermark, abort word, per-granule wave counts
@@ -87,7 +87,10 @@ struct CurvefitArgs {
     double p0s[kMaxP], los[kMaxP], his[kMaxP], fixeds[kMaxP];
     int free_idx[kMaxP];
     int fixed_idx[kMaxP];
+    int use_sigma;       // curve_fit(sigma = 1-D): residual and Jacobian rows are scaled by w[i] = 1 / sigma_i (scipy:_minpack_py.py:958-960, 545-562)
+    int absolute_sigma;  // curve_fit(absolute_sigma = True): the covariance is not scaled by 2 cost / (n_b - n_free) (:1057-1063)
     double b[kMaxB];
+    double w[kMaxB];     // 1 / sigma per measurement (use_sigma only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -681,11 +684,15 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
     double *bsh = smem;                                   // [kMaxB]
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    double *ytile = smem + kMaxB + (size_t)wave * PK::per_wave(n_b);       // [ceil(n_b/2)][64][2], wave-uniform base
+    const bool use_w = A.use_sigma != 0;                  // wave uniform: a scalar branch per row, nothing else changes without sigma
+    const double *wsh = smem + kMaxB;                     // [kMaxB] 1 / sigma per measurement -- only allocated with sigma
+    double *ytile = smem + (use_w ? 2 * kMaxB : kMaxB) + (size_t)wave * PK::per_wave(n_b);  // [ceil(n_b/2)][64][2], wave-uniform base
     double *ysh = ytile + 2 * lane;                                         // this lane's pair column
     double *rpark = ytile + (size_t)((n_b + 1) & ~1) * kWave + lane;        // [NR][64]
     double *vpark = rpark + (size_t)PK::NR * kWave;                           // [NV][64]
     for (int i = threadIdx.x; i < n_b; i += blockDim.x) bsh[i] = A.b[i];
+    if (use_w)
+        for (int i = threadIdx.x; i < n_b; i += blockDim.x) smem[kMaxB + i] = A.w[i];
     __syncthreads();
     // the refill uses asynchronous 16-byte global->LDS loads, one per pair of b-values.  The global side needs no more than the
     // 8-byte alignment every row of doubles has (rows of an odd number of b-values start on odd multiples of 8), and the last
@@ -922,7 +929,7 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
 #pragma unroll
                     for (int c = 0; c < NC; ++c) E[c] = exp_fast(nb * pe[M::dpos(c)]);
                     const double base = M::signal(pe, E);
-                    const double r0 = (T1 ? base * A1 * eTM : base) - yi;
+                    double r0 = (T1 ? base * A1 * eTM : base) - yi;
                     double jr[N];
                     {
                         double ja[NP];
@@ -957,6 +964,12 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
 #pragma unroll
                             for (int k = 0; k < NALL; ++k) ja[k] *= fac;
                             ja[NP - 1] = base * dfac;
+                        }
+                        if (use_w) {  // transform * (f - y), transform[:, None] * jac (the 2-point quotient of scaled residuals)
+                            const double t = wsh[ii];
+                            r0 *= t;
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) ja[k] *= t;
                         }
                         if (HASFIXED) {
 #pragma unroll
@@ -1227,7 +1240,7 @@ __global__ void __launch_bounds__(64 * PNX_CF_BLOCK_WAVES, PNX_CF_WAVES_PER_SIMD
 // ---------------------------------------------------------------------------------------------
 // Covariance epilogue (one lane per voxel, fully convergent): turns the packed R factor of the final
 // Jacobian that curvefit_kernel parked in pcov[vox] into SciPy's pcov
-//   pinv(J^T J) * 2 cost / (m - n)   with singular values <= eps * max(m, n) * s_max dropped
+//   pinv(J^T J) * 2 cost / (m - n)   with singular values <= eps * max(m, n) * s_max dropped  (absolute_sigma: unscaled)
 // (scipy/optimize/_minpack_py.py:1036-1066), NaN for failed voxels (curvefit.py:236-243, 312-317).
 // ---------------------------------------------------------------------------------------------
 struct ColPerm {
@@ -1236,7 +1249,7 @@ struct ColPerm {
 
 template <int N>
 __global__ void __launch_bounds__(256) pcov_kernel(double *pcov, const int8_t *status, const double *cost,
-                                                   long long n_vox, int n_b, const ColPerm cp) {
+                                                   long long n_vox, int n_b, const ColPerm cp, int absolute_sigma) {
     const long long vox = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (vox >= n_vox) return;
     double *pc = pcov + (size_t)vox * N * N;
@@ -1268,8 +1281,8 @@ __global__ void __launch_bounds__(256) pcov_kernel(double *pcov, const int8_t *s
         sm = fmax(sm, nn);
     }
     const double thr = kEps * (n_b > N ? n_b : N) * sqrt(sm);
-    const bool dof = n_b > N;
-    const double s_sq = dof ? 2.0 * cost[vox] / (double)(n_b - N) : 0.0;
+    const bool dof = absolute_sigma || n_b > N;  // absolute_sigma: no scaling, hence no degrees-of-freedom condition (_minpack_py.py:1057-1063)
+    const double s_sq = absolute_sigma ? 1.0 : (dof ? 2.0 * cost[vox] / (double)(n_b - N) : 0.0);
     double wgt[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) wgt[k] = (sqrt(s2[k]) > thr) ? 1.0 / (s2[k] * s2[k]) : 0.0;  // V_k V_k^T / s_k^2 = w_k w_k^T / s_k^4

@@ -25,6 +25,8 @@
 //     iteration, two 16-byte loads per lane and row, 4 rows in flight.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -827,7 +829,7 @@ __global__ void basis_kernel(const double *b, const double *bins, int nm, int n,
 
 // rows 0..kLdsRows-1 of M plus a 64-entry broadcast buffer (a uniform-address ds_read_b64 replaces two v_readlane)
 static size_t nnls_lds_bytes() {
-    static const size_t pad = getenv("PNX_NNLS_LDS_PAD") ? (size_t)atoi(getenv("PNX_NNLS_LDS_PAD")) : 0;  // occupancy experiments
+    static const size_t pad = dev_getenv("PNX_NNLS_LDS_PAD") ? (size_t)atoi(dev_getenv("PNX_NNLS_LDS_PAD")) : 0;  // occupancy experiments
     return sizeof(double) * (kLdsTri + kW) + pad;
 }
 static_assert(kLdsTri >= 2 + kNnlsWideBins + 2, "the epilogue's bin-ordered scratch aliases the LDS rows of M");
@@ -850,6 +852,83 @@ static bool toeplitz_band(const double *reg, int n_reg, int n_bins, double (&c)[
 }
 
 
+// ---- slabs shared by the block-kernel plans of a device (pnx_nnls.hpp) ---------------------------------------------
+namespace {
+struct SharedSlabs {
+    std::mutex mu;
+    int refs = 0;
+    double *blk4 = nullptr, *gram = nullptr;
+    size_t blk4_bytes = 0, gram_bytes = 0;
+    hipEvent_t last = nullptr;       // recorded behind the last launch that used the slabs ...
+    hipStream_t last_stream = nullptr;  // ... on this stream
+    bool used = false;
+};
+constexpr int kMaxSharedDevices = 64;
+SharedSlabs g_shared[kMaxSharedDevices];
+}  // namespace
+
+int nnls_shared_slabs_get(int device, size_t blk4_bytes, size_t gram_bytes, double **blk4, double **gram) {
+    if (device < 0 || device >= kMaxSharedDevices) return set_error(PNX_ERR_INVALID, "device %d", device);
+    SharedSlabs &S = g_shared[device];
+    std::lock_guard<std::mutex> lk(S.mu);
+    if (S.blk4 && (S.blk4_bytes < blk4_bytes || S.gram_bytes < gram_bytes)) {
+        if (S.refs) return set_error(PNX_ERR_NOMEM, "device %d: shared NNLS slabs are in use at another size", device);
+        (void)hipFree(S.blk4);
+        (void)hipFree(S.gram);
+        S.blk4 = S.gram = nullptr;
+    }
+    if (!S.blk4) {
+        PNX_HIPN(hipMalloc(&S.blk4, blk4_bytes));
+        PNX_HIPN(hipMemset(S.blk4, 0, blk4_bytes));  // the block sweeps read whole blocks, also rows nobody has written yet: finite
+        PNX_HIPN(hipMalloc(&S.gram, gram_bytes));
+        S.blk4_bytes = blk4_bytes;
+        S.gram_bytes = gram_bytes;
+        if (!S.last) PNX_HIPN(hipEventCreateWithFlags(&S.last, hipEventDisableTiming));
+        S.used = false;
+    }
+    S.refs += 1;
+    *blk4 = S.blk4;
+    *gram = S.gram;
+    return PNX_OK;
+}
+void nnls_shared_slabs_put(int device) {
+    if (device < 0 || device >= kMaxSharedDevices) return;
+    std::lock_guard<std::mutex> lk(g_shared[device].mu);
+    if (g_shared[device].refs > 0) g_shared[device].refs -= 1;
+}
+int nnls_shared_slabs_trim(int device) {
+    if (device < 0 || device >= kMaxSharedDevices) return 1;
+    SharedSlabs &S = g_shared[device];
+    std::lock_guard<std::mutex> lk(S.mu);
+    if (S.refs) return 0;  // a plan holds them: kept
+    if (S.blk4) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        (void)hipFree(S.blk4);  // synchronises the device: nothing enqueued still uses them
+        (void)hipFree(S.gram);
+        (void)hipSetDevice(cur);
+        S.blk4 = S.gram = nullptr;
+        S.blk4_bytes = S.gram_bytes = 0;
+        S.used = false;
+    }
+    return 1;
+}
+NnlsSharedUse::NnlsSharedUse(const NnlsPlanData *P_, hipStream_t stream_) : P(P_ && P_->shared_slabs ? P_ : nullptr), stream(stream_) {
+    if (!P) return;
+    SharedSlabs &S = g_shared[P->device];
+    S.mu.lock();
+    if (S.used && S.last_stream != stream) (void)hipStreamWaitEvent(stream, S.last, 0);
+}
+NnlsSharedUse::~NnlsSharedUse() {
+    if (!P) return;
+    SharedSlabs &S = g_shared[P->device];
+    (void)hipEventRecord(S.last, stream);
+    S.last_stream = stream;
+    S.used = true;
+    S.mu.unlock();
+}
+
 int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
                    int device, int cus) {
     P->device = device;
@@ -857,7 +936,7 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     P->n_meas = n_meas;
     P->n_bins = n_bins;
     P->n_reg = n_reg;
-    if (!toeplitz_band(reg, n_reg, n_bins, P->rc, &P->rhb) || getenv("PNX_NNLS_GENERIC_REG")) P->rhb = 0;
+    if (!toeplitz_band(reg, n_reg, n_bins, P->rc, &P->rhb) || dev_getenv("PNX_NNLS_GENERIC_REG")) P->rhb = 0;
     {   // reg_order = 0 (the reference's default) is an all-zero matrix: without regulariser rows the Gram form squares a
         // condition number of ~1e16 -- those fits go through the QR-based kernel
         bool zero = true;
@@ -865,7 +944,7 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
         // up to 64 measurements with Q and R in LDS, 65 .. 128 with both in a per-wave global slab (pnx_nnls_qr.hip): never a
         // silently different algorithm, and since round 4 no refusal either -- the reference's default has no limit on the
         // number of b-values (nnls_solver.py:37, 88-127)
-        P->qr = zero && !getenv("PNX_NNLS_NO_QR");
+        P->qr = zero && !dev_getenv("PNX_NNLS_NO_QR");
     }
     // more than 256 bins: the wide instantiations (eight bins per lane) of this file's kernel and of the QR-form kernels; no block
     // kernel (its LDS copy of the basis would leave room for two voxels per CU), no MFMA Gram step (A^T y on the VALU)
@@ -923,14 +1002,19 @@ int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis,
     // regularisers: supports beyond 128 bins), on the whole call (A^T y on the VALU either way): the full grid of slabs (1 GB),
     // but no 2 GiB chunk buffer for the Gram step unless pnx_nnls_aty asks for one later
     if (P->qr) P->n_waves = 1;  // a QR-form plan never launches this kernel
-    PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * P->mglob_stride * sizeof(double)));
+    if (P->blk) {  // the slabs of the kernels behind the first pass: one set per device (pnx_nnls.hpp)
+        const int rs = nnls_shared_slabs_get(device, nnls_blk4_slab_bytes(P), (size_t)P->n_waves * P->mglob_stride * sizeof(double), &P->Mblk4, &P->Mglob);
+        if (rs != PNX_OK) return rs;
+        P->shared_slabs = true;
+    } else
+        PNX_HIPN(hipMalloc(&P->Mglob, (size_t)P->n_waves * P->mglob_stride * sizeof(double)));
     if (wide && !P->qr) {  // the hand-over pass of a wide plan (passive sets beyond 256 positions): one wave per CU, 1 MB of slab each
         P->wide_waves = cus;
         PNX_HIPN(hipMalloc(&P->Mwide, (size_t)P->wide_waves * glob_tri<8>() * sizeof(double)));
         P->blk_bail_cap = (size_t)kAtyChunk;
         PNX_HIPN(hipMalloc(&P->blk_bail, (P->blk_bail_cap + 1) * sizeof(int32_t)));
     }
-    P->mfma_ok = !getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64 && !wide;  // LDS stage of Bp: n_meas * 2 KiB
+    P->mfma_ok = !dev_getenv("PNX_NNLS_NO_MFMA") && n_meas <= 64 && !wide;  // LDS stage of Bp: n_meas * 2 KiB
     if (P->mfma_ok) {
         if (!P->blk) PNX_HIPN(hipMalloc(&P->aty, (size_t)kAtyChunk * kNnlsMaxBins * sizeof(double)));
         PNX_HIPN(hipFuncSetAttribute((const void *)nnls_aty_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -944,9 +1028,13 @@ void nnls_plan_free(NnlsPlanData *P) {
     if (P->Bp) (void)hipFree(P->Bp);
     if (P->RT) (void)hipFree(P->RT);
     if (P->G) (void)hipFree(P->G);
-    if (P->Mglob) (void)hipFree(P->Mglob);
+    if (P->shared_slabs)
+        nnls_shared_slabs_put(P->device);
+    else {
+        if (P->Mglob) (void)hipFree(P->Mglob);
+        if (P->Mblk4) (void)hipFree(P->Mblk4);
+    }
     if (P->Mblk) (void)hipFree(P->Mblk);
-    if (P->Mblk4) (void)hipFree(P->Mblk4);
     if (P->blk4_bail) (void)hipFree(P->blk4_bail);
     if (P->Mwide) (void)hipFree(P->Mwide);
     if (P->qr_slab) (void)hipFree(P->qr_slab);
@@ -1048,6 +1136,7 @@ int nnls_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_
     a.redo_list = list;
     a.redo_count = count;
     a.bail = nullptr;
+    NnlsSharedUse use(P, stream);  // block-kernel plans: Mglob is the device's shared slab
     PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
     // the plan's persistent grid: with an empty list a wave costs one queue pull
     long long grid = P->n_waves;
@@ -1081,6 +1170,7 @@ int nnls_routed_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int ma
     a.redo_list = a.redo_count = nullptr;
     a.bail = nullptr;
     a.route = route;
+    NnlsSharedUse use(P, stream);
     PNX_HIPN(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), stream));
     long long grid = P->n_waves;
     if (grid > n_vox) grid = n_vox;

@@ -42,6 +42,24 @@ struct NnlsPlanData {
     size_t blk_bail_cap = 0;      // voxels the list can hold
     int32_t *route = nullptr;     // block-kernel plans: [0] the route the pilot of the current call chose (0: block kernel, 1: Gram-form kernel), device
     unsigned long long *queue = nullptr;
+    bool shared_slabs = false;    // block-kernel plans: Mblk4 and Mglob belong to the device's shared slab set (below), not to the plan
+};
+
+// The slabs of the two kernels BEHIND a block-kernel plan's first pass -- the four-slot block kernel (0.55 GB) and the Gram-form
+// kernel that remains its last resort (1 GB) -- exist once per device, for every such plan on it: they are only used by the
+// hand-over pass (one voxel in 10^4 on the reference workload) and by calls the pilot routes to the four-slot kernel, so N plans
+// cost 1.55 GB + N x 0.2 GB (the two-slot kernel's own slabs), not N x 1.8 GB.  Uses are ordered on the device: a launch that
+// touches them waits for the event recorded behind the previous one (another plan, another stream), enqueue order = host order
+// under the set's mutex; everything stays asynchronous.  The set stays allocated while idle (a plan per call -- api.nnls,
+// pnx_nnls_batch_f64 -- would otherwise pay 1.55 GB of hipMalloc + memset each time); pnx_release_staging(device) frees it.
+int nnls_shared_slabs_get(int device, size_t blk4_bytes, size_t gram_bytes, double **blk4, double **gram);
+void nnls_shared_slabs_put(int device);
+int nnls_shared_slabs_trim(int device);  // frees the set unless a plan holds it (returns 0 then, 1 otherwise)
+struct NnlsSharedUse {  // brackets the enqueue of launches that use the shared slabs on `stream`
+    NnlsSharedUse(const NnlsPlanData *P, hipStream_t stream);
+    ~NnlsSharedUse();
+    const NnlsPlanData *P;
+    hipStream_t stream;
 };
 
 int nnls_plan_init(NnlsPlanData *P, int n_meas, int n_bins, const double *basis, const double *reg, int n_reg,
@@ -62,6 +80,7 @@ bool nnls_blk_applicable(const NnlsPlanData *P);
 int nnls_blk_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                          int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream);
 int nnls_blk_plan_init(NnlsPlanData *P);
+size_t nnls_blk4_slab_bytes(const NnlsPlanData *P);  // of the four-slot kernel's grid on this plan's device (after nnls_blk_plan_init)
 // Deferred hand-over (host-array calls made of several chunks, pnx_api.hip): the block kernel appends the voxels it hands over
 // to `bail` with their index within the whole call (`base` + index within this chunk), a gather keeps their signal rows in
 // `y_side`, and the caller solves them in one pass at the end instead of one pass per chunk.

@@ -93,26 +93,29 @@ namespace pnx {
     } while (0)
 
 bool nnls_blk_applicable(const NnlsPlanData *P) {
-    return P->rhb != 0 && P->n_meas <= blk2::kBMeas && P->n_reg == P->n_bins && !getenv("PNX_NNLS_NO_BLK");
+    return P->rhb != 0 && P->n_meas <= blk2::kBMeas && P->n_reg == P->n_bins && !dev_getenv("PNX_NNLS_NO_BLK");
 }
 
 // scratch of the block kernels: one workgroup per CU, Variant::mslab doubles of M per wave (zero initialised: the block sweeps
-// read whole blocks, also rows no voxel of this wave has written yet)
+// read whole blocks, also rows no voxel of this wave has written yet).  slab == nullptr: the grid only (the four-slot kernel's
+// slabs are the device's shared set, pnx_nnls.hpp)
 template <class V> static int blk_variant_init(const NnlsPlanData *P, int *groups, double **slab) {
     PNX_HIPB(hipFuncSetAttribute(V::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds_bytes()));
     int occ = 0;
     PNX_HIPB(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, V::kernel(), V::waves * kW, V::lds_bytes()));
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls block kernel does not fit on a CU");
     *groups = occ * P->cus;
+    if (!slab) return PNX_OK;
     const size_t bytes = (size_t)*groups * V::waves * V::mslab * sizeof(double);
     PNX_HIPB(hipMalloc(slab, bytes));
     PNX_HIPB(hipMemset(*slab, 0, bytes));
     return PNX_OK;
 }
+size_t nnls_blk4_slab_bytes(const NnlsPlanData *P) { return (size_t)P->blk4_groups * blk4::Variant::waves * blk4::Variant::mslab * sizeof(double); }
 int nnls_blk_plan_init(NnlsPlanData *P) {
     int r;
     if ((r = blk_variant_init<blk2::Variant>(P, &P->blk_groups, &P->Mblk))) return r;
-    if ((r = blk_variant_init<blk4::Variant>(P, &P->blk4_groups, &P->Mblk4))) return r;
+    if ((r = blk_variant_init<blk4::Variant>(P, &P->blk4_groups, nullptr))) return r;
     P->blk_bail_cap = (size_t)kAtyChunk;
     PNX_HIPB(hipMalloc(&P->blk_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));   // [0]: count, [1 ..]: voxel indices
     PNX_HIPB(hipMalloc(&P->blk4_bail, (1 + P->blk_bail_cap) * sizeof(int32_t)));  // the same for what blk4 hands to the Gram-form kernel
@@ -181,13 +184,14 @@ static int blk_launch(const BlkCall &C, int64_t off, int64_t c, long long vox_ba
     for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
     a.rhb = P->rhb;
     a.test_rej_k = a.test_rej_n = 0;
-    if (const char *t = V::max_pos == 128 ? getenv("PNX_NNLS_TEST_REJECT") : nullptr) {  // the hand-over target runs without the hook (as the oracle's restatement of the hand-over does)
+    if (const char *t = V::max_pos == 128 ? dev_getenv("PNX_NNLS_TEST_REJECT") : nullptr) {  // the hand-over target runs without the hook (as the oracle's restatement of the hand-over does)
         if (sscanf(t, "%d,%d", &a.test_rej_k, &a.test_rej_n) != 2 || a.test_rej_k < 1 || a.test_rej_n < 1) a.test_rej_k = a.test_rej_n = 0;
     }
     a.route = route;
     a.route_want = route_want;
     a.redo_list = list;
     a.redo_count = count;
+    NnlsSharedUse use(V::max_pos == 128 ? nullptr : P, C.stream);  // the four-slot kernel's slabs are the device's shared set
     PNX_HIPB(hipMemsetAsync(P->queue, 0, sizeof(unsigned long long), C.stream));
     const int groups = V::max_pos == 128 ? P->blk_groups : P->blk4_groups;
     long long grid = (c + V::waves - 1) / V::waves;
@@ -201,7 +205,7 @@ static int blk_launch(const BlkCall &C, int64_t off, int64_t c, long long vox_ba
 // what blk4 itself gives up (a ninth rejected candidate in one outer iteration: test hook only) goes to the Gram-form kernel.
 int nnls_blk_redo_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int max_iter, double *coeff_d, double *rnorm_d,
                          int8_t *status_d, int32_t *iters_d, const int32_t *list, const int32_t *count, hipStream_t stream) {
-    if (getenv("PNX_BLK_NO_WIDE"))  // (A/B) the round-4 hand-over target
+    if (dev_getenv("PNX_BLK_NO_WIDE"))  // (A/B) the round-4 hand-over target
         return nnls_redo_device(P, n_vox, y_d, max_iter, coeff_d, rnorm_d, status_d, iters_d, list, count, stream);
     const BlkCall C{P, y_d, coeff_d, rnorm_d, status_d, iters_d, max_iter, stream};
     PNX_HIPB(hipMemsetAsync(P->blk4_bail, 0, sizeof(int32_t), stream));
@@ -230,15 +234,15 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
     // a drain tail of ~1.4 ms (C4 volume: 488.2 ms in four launches of 2^20 voxels, 484.1 ms in one; PNX_BLK_CHUNK_LOG2 = 20
     // brings the launches of kAtyChunk voxels back)
     int64_t chunk = n_vox;
-    if (const char *t = getenv("PNX_BLK_CHUNK_LOG2")) {
+    if (const char *t = dev_getenv("PNX_BLK_CHUNK_LOG2")) {
         const int l2 = atoi(t);
         if (l2 >= 10 && l2 <= 30) chunk = (int64_t)1 << l2;
     }
     // the pilot (see blk_route_kernel): in the first chunk of a call; the later chunks of a host-array call follow its route
     // (they run on the same stream, behind it)
     int permille = 150;  // the two-pass plan (blk2, then blk4 for what it hands over) against one pass of blk4, by share handed over: equal at ~14 % (profiles/nnls_mu_probe.py)
-    if (const char *t = getenv("PNX_BLK_ROUTE_PERMILLE")) permille = atoi(t);  // <= 0: no pilot, blk2 first for everything
-    const bool wide_route = !getenv("PNX_BLK_NO_WIDE");
+    if (const char *t = dev_getenv("PNX_BLK_ROUTE_PERMILLE")) permille = atoi(t);  // <= 0: no pilot, blk2 first for everything
+    const bool wide_route = !dev_getenv("PNX_BLK_NO_WIDE");
     const bool first = !defer || defer->base == 0;
     const int64_t pilot = (permille > 0 && first && n_vox >= 4 * kBlkPilot) ? kBlkPilot : 0;
     const int32_t *route = nullptr;
@@ -249,7 +253,7 @@ int nnls_blk_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int
         if ((r = blk_launch<blk2::Variant>(C, 0, pilot, base, n_bail, bail, nullptr, 0, nullptr, nullptr))) return r;
         hipLaunchKernelGGL(blk_route_kernel, dim3(1), dim3(1), 0, stream, n_bail, (int)pilot, permille, P->route);
         PNX_HIPB(hipGetLastError());
-        if (getenv("PNX_BLK_ROUTE_DEBUG")) {  // diagnostic (synchronises): what the pilot saw
+        if (dev_getenv("PNX_BLK_ROUTE_DEBUG")) {  // diagnostic (synchronises): what the pilot saw
             int32_t cnt = 0, rt = 0;
             PNX_HIPB(hipStreamSynchronize(stream));
             PNX_HIPB(hipMemcpy(&cnt, n_bail, sizeof(cnt), hipMemcpyDeviceToHost));

@@ -1,13 +1,6 @@
 // pnx_nnls_blk_kernel.hpp -- body of the NNLS block kernel (see pnx_nnls_blk.hip, which includes this file once per instantiation).
 // The includer defines: PNX_BLK_NS (namespace of the instantiation), PNX_BLK_KERNEL (kernel name), PNX_BLK_PS (register slots of a
 // position-indexed vector: 2 or 4), PNX_BLK_WAVES (waves per workgroup = per CU), PNX_BLK_LDS_ROWS (rows of M kept in LDS).
-#undef PNX_BLK_KT
-#undef PNX_BLK_MEET
-#if defined(PNX_BLK_KILLTEST) && PNX_BLK_PS == 2  // (experiment builds) the two-slot instantiation only
-#define PNX_BLK_KT PNX_BLK_KILLTEST
-#else
-#define PNX_BLK_KT 0
-#endif
 namespace pnx {
 namespace PNX_BLK_NS {
 
@@ -373,9 +366,6 @@ __device__ __forceinline__ double bx_gather(const double *Bl, const double *xbuf
 }
 // out[s] (bin binof(lane, s)) = sum_m B[m][bin] v[m] as bt_times; `between` runs behind the first eight row reads
 // rows >= n_meas of the LDS basis are zero: the product stops at `mrows` = n_meas rounded up to the eight rows of a loop step
-#ifndef PNX_BLK_GB
-#define PNX_BLK_GB 0
-#endif
 typedef double dbl2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const dbl2v glb_cdbl2v;
 template <class F>
@@ -383,41 +373,20 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) out[s] = 0;
     const double *col = Bl + 2 * lane;
-    // (experiment PNX_BLK_GB) some rows of the basis come through the vector memory path (L1 / L2), which this kernel leaves idle,
-    // instead of LDS: 1 = rows 0..3, 2 = rows 0..7, 3 = rows 4..7 of every step of eight (half of the basis)
-    const glb_double *gcol = (const glb_double *)kargs()->Bp + 2 * lane;
-    auto gl2 = [&](int row, int half) {
-        const dbl2v t = *reinterpret_cast<glb_cdbl2v *>(gcol + row * kNnlsMaxBins + 128 * half);
-        return double2{t.x, t.y};
-    };
     double2 c0[4], c1[4], d0[4], d1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (PNX_BLK_GB == 1 || PNX_BLK_GB == 2) {
-            c0[r] = gl2(r, 0);
-            c1[r] = gl2(r, 1);
-        } else {
-            c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
-            c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
-        }
-    }
-    if (PNX_BLK_GB == 2 || PNX_BLK_GB == 3) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d0[r] = gl2(4 + r, 0);
-            d1[r] = gl2(4 + r, 1);
-        }
+        c0[r] = *reinterpret_cast<const double2 *>(col + r * kBStride);
+        c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
     }
     between();
 #pragma unroll 1
     for (int m = 0; m < mrows; m += 8) {
         const double *nx = col + (m + 4) * kBStride;
-        if (!((PNX_BLK_GB == 2 && m == 0) || PNX_BLK_GB == 3)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
-                d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
-            }
+        for (int r = 0; r < 4; ++r) {
+            d0[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride);
+            d1[r] = *reinterpret_cast<const double2 *>(nx + r * kBStride + 128);
         }
         {
             const double2 v01 = *reinterpret_cast<const double2 *>(v + m);
@@ -447,14 +416,6 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
                 out[1] = fma(d0[r].y, vv[r], out[1]);
                 out[2] = fma(d1[r].x, vv[r], out[2]);
                 out[3] = fma(d1[r].y, vv[r], out[3]);
-            }
-        }
-        if (PNX_BLK_GB == 3) {  // the next step's rows 4 .. 7 (the last step re-reads rows 4 .. 7: unused)
-            const int mg = ((m + 8) & (kBMeas - 1)) + 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d0[r] = gl2(mg + r, 0);
-                d1[r] = gl2(mg + r, 1);
             }
         }
     }
@@ -495,7 +456,7 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
 // a fifth of the vector instructions and one or two round trips instead of eight.  A^T y is this voxel's dual at p = 0 (the residual
 // form with x = 0), kept in registers.  Same quantity in another summation order; the factor M already comes from the same G.
 #ifndef PNX_BLK_GRAMP
-#define PNX_BLK_GRAMP 0
+#define PNX_BLK_GRAMP 16  // measured 12 / 16 / 20 / 24 / 32: 8.92 / 9.01 / 9.02 / 9.03 / 8.59 M voxels/s (0: 8.52; profiles/r05_nnls_experiments.md, section 3)
 #endif
 constexpr int kGramP = PNX_BLK_GRAMP;
 static_assert(kGramP >= 0 && kGramP < kW, "the Gram-form dual reads positions of the first register slot only");
@@ -512,9 +473,6 @@ __device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, 
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) w[s] = w0[s];
     dbl2v ga[4][2], gb[4][2];
-#if defined(PNX_BLK_GRAM3)
-    dbl2v gc3[4][2];
-#endif
     auto load4 = [&](int k, dbl2v (&g)[4][2]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -535,18 +493,6 @@ __device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, 
             w[3] = fma(xk, g[u][1].y, w[3]);
         }
     };
-#if defined(PNX_BLK_GRAM3)  // (A/B) twelve rows in flight
-    load4(0, ga);
-    if (p > 4) load4(4, gb);
-    for (int k = 0; k < p; k += 12) {
-        if (k + 8 < p) load4(k + 8, gc3);
-        use4(k, ga);
-        if (k + 12 < p) load4(k + 12, ga);
-        if (k + 4 < p) use4(k + 4, gb);
-        if (k + 16 < p) load4(k + 16, gb);
-        if (k + 8 < p) use4(k + 8, gc3);
-    }
-#else
     load4(0, ga);
     for (int k = 0; k < p; k += 8) {
         if (k + 4 < p) load4(k + 4, gb);
@@ -554,7 +500,6 @@ __device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, 
         if (k + 8 < p) load4(k + 8, ga);
         if (k + 4 < p) use4(k + 4, gb);
     }
-#endif
 }
 
 // blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
@@ -854,26 +799,6 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
     }
 }
 
-#if PNX_BLK_KT >= 3
-// (experiment) a meeting point of PNX_BLK_KT_GROUP waves through two LDS words: cnt counts arrivals, zm holds a bit per wave of the
-// group that has run out of voxels (such a wave keeps arriving until the whole group has: then zm is full and everybody leaves)
-#ifndef PNX_BLK_KT_GROUP
-#define PNX_BLK_KT_GROUP 4
-#endif
-typedef __attribute__((address_space(3))) unsigned lds_uint;
-__device__ __noinline__ void group_meet(lds_uint *sync, int lane) {
-    if (lane == 0) {
-        const unsigned old = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned target = old - old % PNX_BLK_KT_GROUP + PNX_BLK_KT_GROUP;
-        while ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0 &&
-               __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (1u << PNX_BLK_KT_GROUP) - 1u)
-            __builtin_amdgcn_s_sleep(2);
-    }
-}
-#define PNX_BLK_MEET() group_meet(kt_sync, lane)
-#elif PNX_BLK_KT
-#define PNX_BLK_MEET() __builtin_amdgcn_s_barrier()
-#endif
 constexpr int kBail = 2;  // internal status: the passive set wants more than kMaxPos columns, the general kernel redoes the voxel
 
 __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {  // read through kargs()
@@ -899,10 +824,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
     M.g = (glb_double *)(kargs()->Mglob + ((size_t)blockIdx.x * kBlkWaves + wave) * kMSlab);
     M.l = (lds_double *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + wave * kLdsMDoubles);
     for (int e = lane; e < kLdsMDoubles; e += kW) M.l[e] = 0.0;  // rows >= p of M are zero, from the first voxel on
-#if PNX_BLK_KT >= 3
-    lds_uint *kt_sync = (lds_uint *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + kBlkWaves * kLdsMDoubles) + 2 * (wave / PNX_BLK_KT_GROUP);
-    if (threadIdx.x < 16) ((lds_uint *)(dyn_lds + kBlkWaves * kScr + kBMeas * kBStride + kBlkWaves * kLdsMDoubles))[threadIdx.x] = 0u;
-#endif
     for (int e = threadIdx.x; e < kBMeas * kBStride; e += kBlkWaves * kW) {
         const int m = e / kBStride, j = e - m * kBStride;
         Bl[e] = (m < nm && j < kNnlsMaxBins) ? kargs()->Bp[(size_t)m * kNnlsMaxBins + j] : 0.0;
@@ -945,12 +866,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
         COUNT(0, 1);
 
         while (status == 1 && S.p < n && S.p < m_total) {
-#if PNX_BLK_KT  // (experiment, profiles/r05_nnls_experiments.md) what lock-step costs: the waves of a CU (or of a group) meet once per outer iteration (waves that have left the kernel no longer count)
-            PNX_BLK_MEET();
-#if PNX_BLK_KT == 2 || PNX_BLK_KT == 4  // second meeting point (as if between publishing the residuals and reading the products)
-            PNX_BLK_MEET();
-#endif
-#endif
             // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
             COUNT(1, 1);
             COUNT(5, S.p);
@@ -1346,15 +1261,6 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
         }
         STAMP(8);
     }
-#if PNX_BLK_KT >= 3
-    if (lane == 0) __hip_atomic_fetch_or(kt_sync + 1, 1u << (wave % PNX_BLK_KT_GROUP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (;;) {  // out of voxels: keep the group's meeting points complete until every wave of the group is
-        unsigned zm = 0;
-        if (lane == 0) zm = __hip_atomic_load(kt_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((unsigned)__builtin_amdgcn_readfirstlane((int)zm) == (1u << PNX_BLK_KT_GROUP) - 1u) break;
-        group_meet(kt_sync, lane);
-    }
-#endif
 #ifdef PNX_NNLS_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 7)
         printf("STAMP setup=%llu dual_bx=%llu dual_bt=%llu dual_reg=%llu cand+append=%llu sync=%llu alpha=%llu removal_head=%llu removal_rows=%llu mtq=%llu tail=%llu out=%llu\n", seg[0], seg[9], seg[10], seg[1], seg[2], seg[3], seg[4], seg[11], seg[5], seg[6], seg[7], seg[8]);
@@ -1371,7 +1277,7 @@ struct Variant {
     static constexpr int waves = kBlkWaves, mslab = kMSlab, max_pos = kMaxPos;
     static const void *kernel() { return (const void *)PNX_BLK_KERNEL; }
     static void launch(dim3 grid, size_t lds, hipStream_t stream, const BlkArgs &a) { hipLaunchKernelGGL(PNX_BLK_KERNEL, grid, dim3(kBlkWaves * kW), lds, stream, a); }
-    static size_t lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * (kScr + kLdsMDoubles) + 8); }
+    static size_t lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * (kScr + kLdsMDoubles)); }
 };
 
 }  // namespace PNX_BLK_NS

@@ -771,7 +771,7 @@ int nnls_qr_solve_device(NnlsPlanData *P, int64_t n_vox, const double *y_d, int 
         // 33 .. 64 measurements fit the LDS kernel (MP = 64: 67 KB, two waves per CU), but the slab kernel with its eight waves
         // per CU is the faster one there too: 4.16 against 2.82 M voxels/s at 33 b-values, 2.85 against 1.72 M at 64
         // (profiles/nnls_cliff_probe.py); PNX_NNLS_QR_SLAB_FROM=65 brings the LDS kernel back for comparison
-        static const int slab_from = getenv("PNX_NNLS_QR_SLAB_FROM") ? atoi(getenv("PNX_NNLS_QR_SLAB_FROM")) : 33;
+        static const int slab_from = dev_getenv("PNX_NNLS_QR_SLAB_FROM") ? atoi(dev_getenv("PNX_NNLS_QR_SLAB_FROM")) : 33;
         const bool wide = P->bstride == kNnlsWideBins;
         if (P->n_meas >= slab_from || P->n_meas > 64) return wide ? launch_qr_big<8>(P, a, stream) : launch_qr_big<4>(P, a, stream);
         if (wide) return P->n_meas <= 32 ? launch_qr<32, 8>(P, a, stream) : launch_qr<64, 8>(P, a, stream);

@@ -410,7 +410,7 @@ static int launch_sweep_nt(const SweepArgs<T> &a, int cus, hipStream_t st) {
     const size_t shmem = sizeof(T) * (kMaxB + (size_t)(block / kWave) * kWave * (a.n_b + 1));
     const long long n_tiles = (a.n_vox + kWave - 1) / kWave - a.v_first / kWave;
     long long want = (n_tiles + 3) / 4;
-    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 32;
+    static const int bpc = dev_getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(dev_getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 32;
     long long cap = (long long)cus * bpc;  // memory-bound: ~2048 blocks, grid-stride the rest
     int grid = (int)(want < cap ? want : cap);
     if (grid < 1) grid = 1;
@@ -431,10 +431,10 @@ static int launch_sweep_nt(const SweepArgs<T> &a, int cus, hipStream_t st) {
 }
 
 template <int MODEL, typename T> static int launch_sweep(SweepArgs<T> a, int cus, hipStream_t st) {
-    static const bool generic_only = getenv("PNX_SWEEP_GENERIC") != nullptr;
+    static const bool generic_only = dev_getenv("PNX_SWEEP_GENERIC") != nullptr;
     // 64 blocks of 4 waves per CU: at C3 every wave gets one tile (measured 4 / 8 / 16 / 32 / 64 / 128: 5.51 / 5.59 / 5.59 /
     // 5.52 / 5.70 / 5.74 TB/s -- flat; the hardware's own wave scheduling hides as much as the software pipeline does)
-    static const int bpc = getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 64;
+    static const int bpc = dev_getenv("PNX_SWEEP_BLOCKS_PER_CU") ? atoi(dev_getenv("PNX_SWEEP_BLOCKS_PER_CU")) : 64;
     const long long n_full = a.n_vox / kWave;
     const bool aligned = (reinterpret_cast<uintptr_t>(a.y) % 16) == 0;
     a.v_first = 0;

@@ -28,7 +28,7 @@ _CURVEFIT_MESSAGES = {
     -4: "Residuals are not finite in the initial point.",
 }
 # scipy.optimize.curve_fit / least_squares arguments whose SciPy default is what the kernel computes
-_CURVE_FIT_DEFAULTS = {"sigma": None, "absolute_sigma": False, "check_finite": True, "nan_policy": None, "loss": "linear",
+_CURVE_FIT_DEFAULTS = {"check_finite": True, "nan_policy": None, "loss": "linear",
                        "x_scale": 1.0, "f_scale": 1.0, "tr_solver": None, "full_output": False}
 _NNLS_MESSAGES = {0: "Maximum number of iterations reached.", -2: "array must not contain infs or NaNs"}
 
@@ -132,6 +132,17 @@ class HipCurveFitSolver(CurveFitBase):
         # honour it, so it is refused instead of being dropped silently (keys at their SciPy default are accepted).
         self.xtol = float(solver_kwargs.pop("xtol", 1e-8))
         self.gtol = float(solver_kwargs.pop("gtol", 1e-8))
+        # sigma / absolute_sigma: the two curve_fit arguments the reference's docstring names (curvefit.py:33).  A scalar or 1-D
+        # sigma (one standard deviation per b-value, shared by the voxels) runs in the kernel; a 2-D sigma (covariance matrix of
+        # the measurements: SciPy whitens with its Cholesky factor) is not implemented and refused here, not per voxel
+        self.sigma = solver_kwargs.pop("sigma", None)
+        self.absolute_sigma = bool(solver_kwargs.pop("absolute_sigma", False))
+        if self.sigma is not None:
+            self.sigma = np.asarray(self.sigma, float)
+            if self.sigma.ndim > 1 and self.sigma.size != 1:
+                raise ValueError("HipCurveFitSolver implements a scalar or 1-D sigma (one standard deviation per b-value); "
+                                 "a 2-D sigma is not implemented")
+            self.sigma = self.sigma.reshape(-1)
         for key, default in _CURVE_FIT_DEFAULTS.items():
             if key in solver_kwargs:
                 v = solver_kwargs.pop(key)
@@ -141,7 +152,7 @@ class HipCurveFitSolver(CurveFitBase):
         unknown = set(solver_kwargs) - {"n_pools"}
         if unknown:
             raise ValueError(f"HipCurveFitSolver got solver arguments it cannot honour: {sorted(unknown)} "
-                             "(supported: xtol, gtol, jacobian, device, n_gpus, io_dtype, n_pools)")
+                             "(supported: sigma, absolute_sigma, xtol, gtol, jacobian, device, n_gpus, io_dtype, n_pools)")
         if method != "trf":
             raise ValueError(f"HipCurveFitSolver implements method='trf' only (got {method!r}); "
                              "use the reference CurveFitSolver for 'dogbox' / 'lm'.")
@@ -240,11 +251,11 @@ class HipCurveFitSolver(CurveFitBase):
         if getattr(self, "_closed", True):
             return
         self._closed = True
-        try:
-            for k in range(max(1, int(getattr(self, "n_gpus", 1)))):
-                api.release_staging(int(self.device) + k)
-        except Exception:  # another solver's call is using the set, the device is gone, the interpreter is shutting down ...
-            pass
+        for dev in sorted({_shard_device(int(self.device), k) for k in range(max(1, int(getattr(self, "n_gpus", 1))))}):
+            try:  # per device: one that is busy (another solver's call is using the set) or gone must not keep the others' slabs alive
+                api.release_staging(dev)
+            except Exception:
+                pass
 
     def __enter__(self):
         return self
@@ -270,6 +281,10 @@ class HipCurveFitSolver(CurveFitBase):
         if ydata.ndim > 2:
             raise ValueError(f"ydata must be 1D or 2D array, but got shape {ydata.shape}.")
         p0_a, lo_a, hi_a, per_voxel = self._prepare_p0_bounds(p0, bounds, n_pixels)
+        if self.sigma is not None and self.sigma.size not in (1, xdata.shape[0]):
+            # curve_fit raises "`sigma` has incorrect shape." (scipy:_minpack_py.py:969), which the reference turns into a failed
+            # fit of every voxel with one warning each (curvefit.py:308-317); a usage error is reported once here instead
+            raise ValueError(f"`sigma` has incorrect shape: {self.sigma.size} values for {xdata.shape[0]} b-values.")
 
         all_names = list(self.model._all_param_names)
         # curvefit.py:274: per-pixel fixed values win, else the model's scalar fixed parameters
@@ -314,7 +329,7 @@ class HipCurveFitSolver(CurveFitBase):
     def _run(self, xdata, ydata, p0, lo, hi, per_voxel, fixed_idx, fixed_vals, jac):
         n_vox = ydata.shape[0]
         kw = dict(max_nfev=int(self.max_iter), ftol=float(self.tol), xtol=self.xtol, gtol=self.gtol, jac=jac,
-                  fixed_idx=fixed_idx, **self._kernel_t1)
+                  fixed_idx=fixed_idx, sigma=self.sigma, absolute_sigma=self.absolute_sigma, **self._kernel_t1)
         n_dev = max(1, min(self.n_gpus, n_vox))
         if n_dev == 1:
             return api.curvefit(self._kernel_model, xdata, ydata, p0, lo, hi, fixed_vals=fixed_vals,

@@ -5,6 +5,7 @@ all against the single-chunk call of the same rows, bit for bit.  Rows come from
 rows contain voxels that the block kernel hands over (passive set beyond 128 positions).
     python tests/fuzz_nnls_host.py [n_cases] [seed]      (on a GPU box; 12 fixed-seed cases run in the GPU suite)"""
 from __future__ import annotations
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 
 import os
 import sys

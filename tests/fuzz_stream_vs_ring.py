@@ -6,6 +6,7 @@ upload piece size, download and page-touch thread counts, a small evaluation bud
 bit-identical, and the streamed call must neither time out nor fall back.
     python tests/fuzz_stream_vs_ring.py [n_cases] [seed]          (on a GPU box; 40 fixed-seed cases run in the GPU suite)"""
 from __future__ import annotations
+import os as _os; _os.environ.setdefault("PNX_ENABLE_TEST_HOOKS", "1")  # this script drives developer switches of the library (include/pnx.h, "Environment")
 
 import contextlib
 import io

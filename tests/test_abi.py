@@ -28,11 +28,36 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.ABI_SYMBOLS) == declared
 
 
+def test_library_exports_nothing_but_the_header():
+    """-fvisibility=hidden + PNX_API + a linker version script generated from the header (pyneapple_amd/_build.py): the dynamic
+    symbol table holds the header's functions and nothing else -- no internal pnx_* helper (up to round 4
+    pnx_launch_curvefit_m0..6 leaked), no kernel handle, no template instantiation of the C++ runtime."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert names == _declared_functions(), sorted(set(names) ^ set(_declared_functions()))
+
+
+def test_header_is_c99_and_marks_every_function_exported(tmp_path):
+    import subprocess
+
+    text = open(os.path.join(ROOT, "include", "pnx.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for m in re.finditer(r"^(.*?)\b(pnx_[a-z0-9_]+)\s*\(", body, flags=re.M):
+        assert m.group(1).strip() == "PNX_API int", f"{m.group(2)} is declared without PNX_API"
+    src = tmp_path / "t.c"
+    src.write_text('#include "pnx.h"\nint main(void) { pnx_curvefit_opts o; o.sigma = 0; o.queue_order = 0; return (int)sizeof(o) * 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "t.o")], check=True)
+
+
 def test_version_and_struct_layout():
     lib = _lib.load()
-    assert lib.pnx_version() == 1
-    # int32 x4 + 2*int32[8] + int32 x6 + 5 doubles
-    assert C.sizeof(_lib.CurvefitOpts) == 4 * 4 + 2 * 8 * 4 + 6 * 4 + 5 * 8
+    assert lib.pnx_version() == 2
+    # int32 x4 + 2*int32[8] + int32 x6 + 5 doubles + 2 pointers (sigma on the host, queue_order on the device)
+    assert C.sizeof(_lib.CurvefitOpts) == 4 * 4 + 2 * 8 * 4 + 6 * 4 + 5 * 8 + 2 * 8
+    assert _lib.CurvefitOpts.sigma.offset == 4 * 4 + 2 * 8 * 4 + 6 * 4 + 5 * 8
     for m, n in enumerate([2, 3, 4, 4, 5, 6, 6]):
         assert lib.pnx_model_n_params(m) == n
     assert lib.pnx_model_n_params(99) < 0 and "unknown model" in _lib.last_error()

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _run(args, env=None):
@@ -31,6 +33,25 @@ def test_launcher_spawns_n_ranks_that_partition_one_volume():
     assert n == 256 * 256 * 64
     assert ranks[0]["rows"][0] == 0 and ranks[-1]["rows"][1] == n
     assert all(a["rows"][1] == b["rows"][0] for a, b in zip(ranks[:-1], ranks[1:]))
+
+
+def test_eight_ranks_rehearsal_launcher_row_split_and_cpu_slices():
+    """The N = 8 the driver runs, without a GPU (a GPU box admits at most six processes on its card, so eight ranks cannot be
+    rehearsed there; tests/test_gpu_multi.py runs four on one card): eight fresh ranks, contiguous row ranges that partition the
+    C3 volume exactly, and -- as on a card shared by all ranks -- eight CPU slices that are pairwise disjoint wherever this
+    process may use at least eight CPUs."""
+    r = _run(["--gpus", "8", "--launch-check", "--voxels", "524288"], env={"PNX_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr
+    ranks = sorted((json.loads(l) for l in r.stdout.splitlines() if l.strip()), key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == list(range(8)) and all(d["world"] == 8 for d in ranks)
+    assert sum(d["rows"][1] - d["rows"][0] for d in ranks) == 524288 == ranks[0]["n_vox_total"]
+    assert ranks[0]["rows"][0] == 0 and all(a["rows"][1] == b["rows"][0] for a, b in zip(ranks[:-1], ranks[1:]))
+    import bench
+
+    sets = [bench._cpulist(d["affinity"]["cpus"]) for d in ranks]
+    assert all(sets)
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert all(not (sets[i] & sets[j]) for i in range(8) for j in range(i + 1, 8))
 
 
 def test_launcher_stops_the_other_ranks_when_one_dies():

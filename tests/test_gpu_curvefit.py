@@ -5,7 +5,8 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, pcov_norm_err, rel_err
+from conftest import (CURVEFIT_FIXTURES, G7_FIXTURES, G12_FIXTURES, check_g7, check_g12, g12_case, golden_p0_bounds, load_golden,
+                      pcov_norm_err, rel_err)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -31,6 +32,69 @@ def test_fd_matches_reference_golden(gpu, name):
         if good.any():
             e = pcov_norm_err(r["pcov"][sel][good], d["pcov"][sel][good])
             assert np.median(e) < 1e-5 and (e < 1e-2).mean() > 0.97
+
+
+@pytest.mark.parametrize("name", sorted(G12_FIXTURES))
+def test_sigma_matches_reference_golden(gpu, name):
+    """curve_fit(sigma=..., absolute_sigma=...) as the reference forwards them (solvers/curvefit.py:33, 295-306): the reference's
+    own weighted fits (vector and scalar sigma, FD and analytic Jacobian, both covariance scalings); bar: conftest.check_g12."""
+    d, model, free, kw = g12_case(name)
+    r = gpu.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                     max_nfev=int(d["max_iter"]), ftol=float(d["tol"]), **kw)
+    check_g12(r, d, model, free, kw)
+
+
+@pytest.mark.parametrize("model,n_b,absolute", [("tri_reduced", 32, True), ("bi_reduced", 24, False), ("mono", 15, True)])
+@pytest.mark.parametrize("jac", ["fd", "analytic"])
+def test_sigma_matches_oracle_seeded(gpu, oracle, model, n_b, absolute, jac):
+    """Weighted fits against the oracle on 6 000 seeded voxels per case (the oracle is pinned by the g12 fixtures), host arrays
+    (streamed launch) -- estimates, cost, status, covariance; and float32 storage takes the same sigma (always fp64 on the host)."""
+    from pyneapple_amd import synth
+
+    n_vox = 6000
+    b, y, _ = synth.make_numpy(model, n_vox, n_b, sigma=0.02, seed=321)
+    _, p0, lo, hi = synth.shared_arrays(model)
+    sigma = 0.01 * (1.0 + b / 400.0)
+    r = gpu.curvefit(model, b, y, p0, lo, hi, jac=jac, sigma=sigma, absolute_sigma=absolute)
+    o = oracle.curvefit(model, b, y, p0, lo, hi, jac=jac, sigma=sigma, absolute_sigma=absolute, n_threads=8)
+    assert ((r["status"] > 0) == (o["status"] > 0)).all() and (r["status"] > 0).mean() > 0.99
+    e = rel_err(r["popt"], o["popt"]).max(axis=0)
+    assert (e <= RTOL).mean() >= 0.99 and np.median(e) < 1e-7
+    near = e <= RTOL
+    assert np.allclose(r["cost"][near], o["cost"][near], rtol=1e-6)
+    pe = pcov_norm_err(r["pcov"][near], o["pcov"][near])
+    assert np.nanmedian(pe) < 1e-5
+    plain = gpu.curvefit(model, b, y, p0, lo, hi, jac=jac)
+    assert np.median(rel_err(plain["popt"], r["popt"]).max(axis=0)) > 1e-6  # the weights do change the answer
+    r32 = gpu.curvefit(model, b.astype(np.float32), y.astype(np.float32), p0, lo, hi, jac=jac, sigma=sigma, absolute_sigma=absolute)
+    assert r32["popt"].dtype == np.float32
+    assert np.median(rel_err(r32["popt"].astype(float), r["popt"]).max(axis=0)) < 1e-4
+
+
+def test_sigma_through_the_plugin_and_its_validation(gpu):
+    """HipCurveFitSolver(sigma=..., absolute_sigma=...) -- the keyword arguments of the reference's solver -- equals the array-level
+    call; a 2-D sigma and a sigma of the wrong length are refused with a ValueError."""
+    from pyneapple_amd import synth
+    from pyneapple_amd.models import BiExpModel
+    from pyneapple_amd.solvers import HipCurveFitSolver
+
+    b, y, _ = synth.make_numpy("bi_reduced", 500, 24, sigma=0.02, seed=5)
+    names, p0, lo, hi = synth.shared_arrays("bi_reduced")
+    sigma = 0.01 * (1.0 + b / 400.0)
+    kw = dict(model=BiExpModel(), max_iter=250, tol=1e-8, p0=dict(zip(names, p0)), bounds={n: (l, h) for n, l, h in zip(names, lo, hi)})
+    s = HipCurveFitSolver(sigma=sigma, absolute_sigma=True, **kw).fit(b, y)
+    r = gpu.curvefit("bi_reduced", b, y, p0, lo, hi, sigma=sigma, absolute_sigma=True)
+    np.testing.assert_array_equal(np.stack([s.params_[n] for n in names]), r["popt"])
+    np.testing.assert_array_equal(s.diagnostics_["pcov"], r["pcov"])
+    s1 = HipCurveFitSolver(sigma=0.05, **kw).fit(b, y)  # scalar sigma: the estimates of the unweighted fit (up to the trust-region path)
+    s0 = HipCurveFitSolver(**kw).fit(b, y)
+    assert np.median(rel_err(np.stack([s1.params_[n] for n in names]), np.stack([s0.params_[n] for n in names])).max(axis=0)) < 1e-6
+    with pytest.raises(ValueError, match="2-D sigma"):
+        HipCurveFitSolver(sigma=np.eye(24), **kw)
+    with pytest.raises(ValueError, match="incorrect shape"):
+        HipCurveFitSolver(sigma=np.ones(7), **kw).fit(b, y)
+    z = gpu.curvefit("bi_reduced", b, y[:8], p0, lo, hi, sigma=np.where(np.arange(24) == 3, 0.0, 1.0))
+    assert (z["status"] == -4).all()  # 1 / 0: "Residuals are not finite in the initial point" -> the reference's failure sentinel
 
 
 @pytest.mark.parametrize("name", sorted(G7_FIXTURES))
@@ -587,7 +651,7 @@ def test_two_stalled_uploads_in_a_row_cost_one_stall(gpu, monkeypatch, capfd):
 
 
 def test_queue_order_changes_the_schedule_not_the_results(gpu):
-    """pnx_curvefit_queue_order: the kernel's k-th queue pull fits voxel order[k].  A voxel's arithmetic is its own, so any
+    """pnx_curvefit_opts::queue_order: the kernel's k-th queue pull fits voxel order[k].  A voxel's arithmetic is its own, so any
     permutation gives bit-identical results; the order made from a previous pass's evaluation counts (pnx_queue_order_f64:
     descending, ties in index order) is what a refit of the same volume passes (C3: 34.3 -> 25.0 ms,
     profiles/curvefit_order_probe.py).  The order applies to ONE call."""
@@ -623,10 +687,50 @@ def test_queue_order_changes_the_schedule_not_the_results(gpu):
         got = run(perm)
         for a, r in zip(got, ref):
             assert torch.equal(a, r) or bool(((a == r) | (a.isnan() & r.isnan())).all())
-    again = run()  # the order was for one call only
+    again = run()  # the order is an argument of ONE call (a field of its opts), not state the library keeps
     assert torch.equal(again[0], ref[0])
     with pytest.raises(ValueError):
         api.curvefit_device(opts, n_vox, b, y, p0, lo, hi, None, *ref, 0, s, order=order[:-1])
+
+
+def test_queue_order_leaves_nothing_behind_a_failed_call(gpu):
+    """ Up to round 4 the order was thread-local "next call" state: a device-mode call that failed its argument
+    checks left a dangling pointer behind for the next fit of the thread.  Now: an order, a failing call, then a host-array fit
+    and a device fit, both right; and an order on a host-array call is refused."""
+    import ctypes as C
+
+    import torch
+
+    from pyneapple_amd import _lib, api, synth
+
+    dev = torch.device("cuda", 0)
+    n_vox, n_b = 4096, 32
+    b, y = synth.make_torch("tri_reduced", n_vox, n_b, dev, sigma=0.01, seed=9)
+    names, p0, lo, hi = synth.shared_arrays("tri_reduced")
+    k = len(names)
+    opts = api.make_opts("tri_reduced", n_b)
+    s = torch.cuda.current_stream().cuda_stream
+    order = torch.randperm(n_vox, device=dev).to(torch.int32)
+    popt = torch.empty((k, n_vox), dtype=torch.float64, device=dev)
+    pcov = torch.empty((n_vox, k, k), dtype=torch.float64, device=dev)
+    with pytest.raises(_lib.PnxError, match="status and cost"):  # pcov without status / cost: refused after the order was passed
+        api.curvefit_device(opts, n_vox, b, y, p0, lo, hi, None, popt, pcov, None, None, None, 0, s, order=order)
+    del order
+    torch.cuda.empty_cache()
+    host = gpu.curvefit("tri_reduced", b if isinstance(b, np.ndarray) else np.asarray(b), y.cpu().numpy(), p0, lo, hi)
+    st = torch.empty(n_vox, dtype=torch.int8, device=dev)
+    api.curvefit_device(opts, n_vox, b, y, p0, lo, hi, None, popt, None, st, None, None, 0, s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(popt.cpu().numpy(), host["popt"])
+    assert opts.queue_order is None
+    o2 = api.make_opts("tri_reduced", n_b)
+    o2.queue_order = 12345  # any non-null pointer: a host-array call must refuse it before touching it
+    yh = y.cpu().numpy()
+    out = np.empty((k, n_vox))
+    bb = np.ascontiguousarray(np.asarray(b), np.float64)
+    rc = _lib.load().pnx_curvefit_batch_f64(C.byref(o2), n_vox, _lib.ptr(bb), _lib.ptr(yh), _lib.ptr(p0), _lib.ptr(lo), _lib.ptr(hi), None,
+                                            _lib.ptr(out), None, None, None, None, 0, 0, None)
+    assert rc == -1 and "queue_order" in _lib.last_error()
 
 
 def test_device_call_is_graph_capturable(gpu):

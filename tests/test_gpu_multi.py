@@ -149,6 +149,34 @@ def test_bench_two_ranks_as_child_processes_on_one_card():
         assert f'"{k}": ' in head
 
 
+def test_bench_four_ranks_on_one_card():
+    """ The largest rank count one card admits beside this test process (the pool allows six GPU
+    processes): four ranks, four disjoint CPU slices, four staging sets streaming at once through the PCIe-inclusive leg,
+    voxels_per_rank summing to the volume, one JSON line.  gloo carries the barrier (RCCL needs a device per rank and has
+    never run with more than one: DESIGN.md section 6); the N = 8 launcher / row split / CPU slicing is rehearsed without a GPU
+    in tests/test_bench_sharding.py."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PNX_BENCH_SHARE_GPU="1", PNX_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--voxels", "524288", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["voxels_per_rank"] == [131072] * 4 and sum(d["config"]["voxels_per_rank"]) == 524288
+    assert d["value"] > 0 and d["nnls_voxels_per_s"] > 0 and d["check"]["converged_frac"] > 0.995
+    for hm in (d["host_mode"], d["secondary"]["host_mode"]):
+        assert hm["n_gpus"] == 4 and len(hm["per_rank_pcie_GBps"]) == 4 and min(hm["per_rank_pcie_GBps"]) > 0
+        assert hm["equals_device_resident_result"] is True
+    aff = d["affinity"]
+    assert len(aff) == 4 and all(a and a.get("cpus") for a in aff)
+    import bench
+
+    sets = [bench._cpulist(a["cpus"]) for a in aff]
+    assert all(not (sets[i] & sets[j]) for i in range(4) for j in range(i + 1, 4))
+    assert "noise_sweep" not in d  # N = 1 only
+
+
 def test_bench_two_ranks_under_torch_distributed_run_on_one_card():
     """The driver's own N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...` -- with two ranks on this box's one card (PNX_BENCH_SHARE_GPU, gloo for the barrier

@@ -314,6 +314,39 @@ def test_rejected_candidate_columns_are_set_aside_and_come_back(gpu, oracle, mon
         np.testing.assert_array_equal(again[k], plain[k])
 
 
+def test_developer_switches_are_ignored_without_the_gate(gpu):
+    """include/pnx.h, "Environment": the rejection hook (and every A/B kernel switch) is read only in a process started with
+    PNX_ENABLE_TEST_HOOKS=1.  Three fresh processes solve the same 256 voxels: hook set but no gate = no hook, bit for bit; with
+    the gate the hook sends the solves down other paths (more iterations)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    child = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+        "from pyneapple_amd import api, synth\n"
+        "_, basis, reg = synth.nnls_matrices(32)\n"
+        "_, y, _ = synth.make_numpy('tri_reduced', 256, 32, sigma=0.01, seed=5, scale=1000.0)\n"
+        "r = api.nnls(basis, reg, y, 2000)\n"
+        "print(json.dumps({'iters': int(r['iters'].sum()), 'coef': float(r['coefficients'].sum())}))\n" % ROOT)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("PNX_")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", child], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    plain = run()
+    ungated = run(PNX_NNLS_TEST_REJECT="2,4", PNX_NNLS_NO_BLK="1", PNX_BLK_ROUTE_PERMILLE="1")
+    gated = run(PNX_ENABLE_TEST_HOOKS="1", PNX_NNLS_TEST_REJECT="2,4")
+    assert ungated == plain
+    assert gated["iters"] > plain["iters"]
+
+
 def test_host_chunks_defer_the_hand_over_pass(gpu, monkeypatch):
     """Host arrays in several chunks: the block kernel's handed-over voxels (passive set beyond 128 positions) are solved in
     ONE pass at the end of the call and patched into the result arrays.  Same bits as the single-chunk call (hand-over pass

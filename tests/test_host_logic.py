@@ -116,14 +116,17 @@ class TestCurveFitSolverHostSide:
 
     def test_solver_kwargs_are_honoured_or_refused(self):
         """Extra [Fitting.solver] keys reach the constructor as kwargs (io/toml.py:328-338); the reference forwards them to
-        curve_fit (curvefit.py:295-306).  xtol / gtol are implemented, SciPy defaults are accepted, the rest is refused."""
+        curve_fit (curvefit.py:295-306).  sigma (scalar or 1-D) / absolute_sigma -- the two its docstring names (curvefit.py:33) --
+        and xtol / gtol are implemented, SciPy defaults are accepted, the rest is refused."""
         kw = dict(model=MonoExpModel(), max_iter=250, tol=1e-8, p0={"S0": 1000.0, "D": 1e-3},
                   bounds={"S0": (1.0, 5000.0), "D": (1e-5, 0.1)})
         s = HipCurveFitSolver(**kw, xtol=1e-10, gtol=1e-6, n_pools=4, multi_threading=True, device=0, n_gpus=1,
                               jacobian="fd", io_dtype="float64", absolute_sigma=False, loss="linear", x_scale=1.0)
-        assert s.xtol == 1e-10 and s.gtol == 1e-6
-        for bad in (dict(sigma=np.ones(8)), dict(loss="soft_l1"), dict(x_scale="jac"), dict(absolute_sigma=True),
-                    dict(typo_key=1)):
+        assert s.xtol == 1e-10 and s.gtol == 1e-6 and s.sigma is None and s.absolute_sigma is False
+        s = HipCurveFitSolver(**kw, sigma=np.ones(8), absolute_sigma=True)
+        assert s.sigma.shape == (8,) and s.absolute_sigma is True
+        assert HipCurveFitSolver(**kw, sigma=0.5).sigma.tolist() == [0.5]
+        for bad in (dict(sigma=np.eye(8)), dict(loss="soft_l1"), dict(x_scale="jac"), dict(typo_key=1)):
             with pytest.raises(ValueError):
                 HipCurveFitSolver(**kw, **bad)
         with pytest.raises(ValueError):

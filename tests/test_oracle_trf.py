@@ -5,8 +5,8 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import (CURVEFIT_FIXTURES, G7_FIXTURES, check_g7, golden_p0_bounds, load_golden, many_fixed_cases,
-                      pcov_norm_err, rel_err)
+from conftest import (CURVEFIT_FIXTURES, G7_FIXTURES, G12_FIXTURES, check_g7, check_g12, g12_case, golden_p0_bounds, load_golden,
+                      many_fixed_cases, pcov_norm_err, rel_err)
 
 RTOL = 1e-4  # BASELINE.json north_star: rtol=1e-4 (fp64) per parameter
 
@@ -41,6 +41,32 @@ def test_oracle_matches_reference_golden_g7(oracle, name):
     r = oracle.curvefit(model, d["bvalues"], d["y"], d["p0_vals"], d["lo_vals"], d["hi_vals"], max_nfev=int(d["max_iter"]),
                         ftol=float(d["tol"]), jac="fd", **kw)
     check_g7(r, d, kw, amp)
+
+
+@pytest.mark.parametrize("name", sorted(G12_FIXTURES))
+def test_oracle_matches_reference_golden_sigma(oracle, name):
+    """curve_fit(sigma=..., absolute_sigma=...): 1-D sigma (vector or scalar) scales residual and Jacobian rows by 1 / sigma
+    (scipy:_minpack_py.py:958-960, 545-562); absolute_sigma leaves the covariance unscaled (:1057-1063)."""
+    d, model, free, kw = g12_case(name)
+    r = oracle.curvefit(model, d["bvalues"], d["y"], d["p0_vals"][free], d["lo_vals"][free], d["hi_vals"][free],
+                        max_nfev=int(d["max_iter"]), ftol=float(d["tol"]), **kw)
+    check_g12(r, d, model, free, kw)
+
+
+def test_oracle_sigma_changes_the_fit_and_the_covariance_scale(oracle):
+    """Guards the fixtures' meaning: with sigma the estimates differ from the unweighted fit, and absolute_sigma only changes
+    the covariance (by the reduced chi square), not the estimates."""
+    d, model, free, kw = g12_case("g12_tri_sigma_abs")
+    a = (model, d["bvalues"], d["y"], d["p0_vals"], d["lo_vals"], d["hi_vals"])
+    plain = oracle.curvefit(*a)
+    w_abs = oracle.curvefit(*a, sigma=kw["sigma"], absolute_sigma=True)
+    w_rel = oracle.curvefit(*a, sigma=kw["sigma"], absolute_sigma=False)
+    noisy = d["sigma"] > 0
+    assert rel_err(w_abs["popt"], plain["popt"]).max(axis=0)[noisy].min() > 1e-6
+    assert np.array_equal(w_abs["popt"], w_rel["popt"]) and np.array_equal(w_abs["cost"], w_rel["cost"])
+    m, n = len(d["bvalues"]), 5
+    s_sq = 2 * w_rel["cost"] / (m - n)
+    assert np.allclose(w_rel["pcov"][noisy], w_abs["pcov"][noisy] * s_sq[noisy, None, None], rtol=1e-12)
 
 
 def test_oracle_fixed_params_golden(oracle):
