@@ -1,7 +1,7 @@
 """A bounded slice of the large-sample evidence inside the GPU suite: 65 536 voxels of the C3 workload and 16 384 of the C4
-workload against the oracle (the full-size runs are profiles/parity_large.py -> profiles/r03_parity_large.json), and 100
-fixed-seed cases of each differential fuzzer (tests/fuzz_gpu_vs_oracle*.py -> profiles/r03_fuzz_*.json).  The thresholds are
-the recorded rates of those runs with a margin; what the rates mean is argued in DESIGN.md section 3."""
+workload against the oracle (the full-size runs are profiles/parity_large.py -> profiles/r05_parity_large.json, one stamped set
+per round), and 100 fixed-seed cases of each differential fuzzer (tests/fuzz_gpu_vs_oracle*.py -> profiles/r05_fuzz_*.json).  The
+thresholds are the recorded rates of those runs with a margin; what the rates mean is argued in DESIGN.md section 3."""
 from __future__ import annotations
 
 import importlib.util
