@@ -526,40 +526,6 @@ template <int NI> __device__ __forceinline__ void block_row(const MRef &M, int I
         if (K <= I) row[K] = 8 * I < kLdsM ? M.l[base + 8 * K] : blk[I][K];
 }
 
-// ---- round 5, four-slot instantiation: block rows 8 .. 15 (rows 64 .. 127) of M in the block sweeps too -----------------------
-// Strong regularisers make supports of 100 - 150 bins the rule; up to round 4 every row beyond 63 went row by row (~22 vector
-// instructions and a quarter of a round trip each: 54 % of the four-slot kernel's time was the append).  All 100 blocks of these
-// rows at once are 200 registers, so they are STREAMED: a block row is up to sixteen blocks = sixteen loads per lane, three block
-// rows are in registers, two of them in flight while one is consumed.  f(I, row) gets block row I with row[K] = block (I, K),
-// K <= I; blocks beyond I are not loaded.
-#ifndef PNX_BLK_STREAM_ROWS
-#define PNX_BLK_STREAM_ROWS 1  // 0: rows >= 64 row by row (up to round 4; A/B builds)
-#endif
-constexpr int kStreamFrom = 8, kStreamTo = 16;  // block rows [8, 16): rows 64 .. 127
-template <class F> __device__ __forceinline__ void stream_block_rows(const MRef &M, int la, int lb, int i_end, F &&f) {
-    auto load_row = [&](int I, double (&row)[kStreamTo]) {
-        const int base = (I + 1) * (32 * I + 8 * la) + lb;
-#pragma unroll
-        for (int K = 0; K < kStreamTo; ++K)
-            if (K <= I) row[K] = M.g[CK(base + 8 * K, kMSlab, 30, I)];  // I is wave uniform: scalar branches
-    };
-    double ra[kStreamTo], rb[kStreamTo], rc[kStreamTo];
-    load_row(kStreamFrom, ra);
-    if (kStreamFrom + 1 <= i_end) load_row(kStreamFrom + 1, rb);
-    for (int I = kStreamFrom; I <= i_end; I += 3) {
-        if (I + 2 <= i_end) load_row(I + 2, rc);
-        f(I, ra);
-        if (I + 1 <= i_end) {
-            if (I + 3 <= i_end) load_row(I + 3, ra);
-            f(I + 1, rb);
-        }
-        if (I + 2 <= i_end) {
-            if (I + 4 <= i_end) load_row(I + 4, rb);
-            f(I + 2, rc);
-        }
-    }
-}
-
 // Column jmax wants to enter.  l = M g (g = G[P, jmax]), lam^2 = G_jj - |l|^2, Lawson-Hanson independence test; when it
 // passes: new row of M = [-(l^T M) / lam, 1 / lam], z = x + row * qn (x == M^T q whenever a column enters), q_p = qn.
 // Returns false when the column is rejected (nothing changed).
@@ -608,49 +574,12 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #pragma unroll
         for (int K = 0; K <= I; ++K) rK[K] = fma(row[K], lr, rK[K]);
     }
-    // four-slot instantiation: block rows 8 .. 15 streamed through the same two products (l = M g, column sums of l^T M)
-    int rows_blockwise = kRows2D;
-    double rK2[kStreamTo - kStreamFrom];  // column blocks 8 .. 15
-#pragma unroll
-    for (int K = 0; K < kStreamTo - kStreamFrom; ++K) rK2[K] = 0;
-    if constexpr (kPS == 4 && PNX_BLK_STREAM_ROWS) {
-        if (NI == kNIMax && p > kRows2D) {
-            const int ps_base = (int)lds_addr(reinterpret_cast<const double *>(ps) + kMaxPos / 2 + 2);
-            double gc2[kStreamTo - kStreamFrom];  // g in column layout for the column blocks 8 .. 15 (behind position p: staged as the zero bin, and those columns of M are zero)
-#pragma unroll
-            for (int K = 0; K < kStreamTo - kStreamFrom; ++K)
-                gc2[K] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(grow) + (unsigned)(ps[8 * (K + kStreamFrom) + lb] - ps_base));
-            const int i_last = (p - 1) >> 3;
-            const int i_end = i_last < kStreamTo - 1 ? i_last : kStreamTo - 1;
-            stream_block_rows(M, la, lb, i_end, [&](int I, const double (&row)[kStreamTo]) {
-                double acc = 0;
-#pragma unroll
-                for (int K = 0; K < kStreamTo; ++K) {
-                    if (K < kStreamFrom)
-                        acc = fma(row[K], gc[K < NI ? K : 0], acc);
-                    else if (K <= I)
-                        acc = fma(row[K], gc2[K - kStreamFrom], acc);
-                }
-                double lr = allreduce_b(acc);
-                lr = (8 * I + la < p) ? lr : 0.0;  // rows >= p of the slab may hold a previous voxel's values
-                ll = fma(lr, lr, ll);
-#pragma unroll
-                for (int K = 0; K < kStreamTo; ++K) {
-                    if (K < kStreamFrom)
-                        rK[K < NI ? K : 0] = fma(row[K], lr, rK[K < NI ? K : 0]);
-                    else if (K <= I)
-                        rK2[K - kStreamFrom] = fma(row[K], lr, rK2[K - kStreamFrom]);
-                }
-            });
-            rows_blockwise = 8 * (i_end + 1);
-        }
-    }
     ll = allreduce_a(ll);
-    // the rows beyond the block-wise part: row by row (lanes over the columns), four rows in flight
+    // rows >= 48: row by row (lanes over the columns), four rows in flight
     double a1[kPS];    // l^T M by position
 #pragma unroll
     for (int s = 0; s < kPS; ++s) a1[s] = 0;
-    if (NI == kNIMax && p > rows_blockwise) {
+    if (NI == kNIMax && p > kRows2D) {
         double g[kPS];
 #pragma unroll
         for (int s = 0; s < kPS; ++s) g[s] = (lane + kW * s < p) ? grow[CK(S.pidx[s], kNnlsMaxBins, 4, p)] : 0.0;
@@ -704,7 +633,7 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
                 for (int s = 0; s <= si; ++s) a1[s] = fma(li, m[r][s], a1[s]);
             }
         };
-        for_pos4n<kPS>(rows_blockwise, p, four, one);
+        for_pos4n<kPS>(kRows2D, p, four, one);
     }
     ll = uni(ll);
     // wave-uniform scalar algebra on v_rsq_f64 + Newton (pnx_nnls.hip)
@@ -729,9 +658,6 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
 #endif
     // column sums over a, delivered in position order (position 8 la + lb is column block K = la)
     a1[0] += reduce_scatter_a<NI>(rK, la);
-    if constexpr (kPS == 4 && PNX_BLK_STREAM_ROWS) {
-        if (NI == kNIMax && rows_blockwise > kRows2D) a1[1] += reduce_scatter_a<kStreamTo - kStreamFrom>(rK2, la);  // column blocks 8 .. 15 = positions 64 .. 127
-    }
     // the new row by position: -(l^T M) / lam in front of position p (beyond it l^T M is zero: those columns of M are), 1 / lam
     // at p.  The masks are scalar (p is wave uniform): no vector compare, and the second register slot only where it is in use.
     {
@@ -842,37 +768,10 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
 #pragma unroll
         for (int K = 0; K <= I; ++K) zK[K] = fma(row[K], qr[I], zK[K]);
     }
+    S.z[0] = reduce_scatter_a<NI>(zK, la);
 #pragma unroll
     for (int s = 1; s < kPS; ++s) S.z[s] = 0;
-    int rows_blockwise = kRows2D;
-    if constexpr (kPS == 4 && PNX_BLK_STREAM_ROWS) {
-        if (NI == kNIMax && p > kRows2D) {  // block rows 8 .. 15 streamed (see stream_block_rows)
-            lds_order();
-            stg[kW + lane] = S.q[1];  // q of the positions 64 .. 127 (the staging buffer holds 2 kMaxPos doubles in this instantiation)
-            lds_order();
-            double zK2[kStreamTo - kStreamFrom];
-#pragma unroll
-            for (int K = 0; K < kStreamTo - kStreamFrom; ++K) zK2[K] = 0;
-            const int i_last = (p - 1) >> 3;
-            const int i_end = i_last < kStreamTo - 1 ? i_last : kStreamTo - 1;
-            stream_block_rows(M, la, lb, i_end, [&](int I, const double (&row)[kStreamTo]) {
-                double qI = stg[8 * I + la];
-                qI = (8 * I + la < p) ? qI : 0.0;
-#pragma unroll
-                for (int K = 0; K < kStreamTo; ++K) {
-                    if (K < kStreamFrom)
-                        zK[K < NI ? K : 0] = fma(row[K], qI, zK[K < NI ? K : 0]);
-                    else if (K <= I)
-                        zK2[K - kStreamFrom] = fma(row[K], qI, zK2[K - kStreamFrom]);
-                }
-            });
-            lds_order();
-            S.z[1] = reduce_scatter_a<kStreamTo - kStreamFrom>(zK2, la);
-            rows_blockwise = 8 * (i_end + 1);
-        }
-    }
-    S.z[0] = reduce_scatter_a<NI>(zK, la);
-    if (NI == kNIMax && p > rows_blockwise) {
+    if (NI == kNIMax && p > kRows2D) {
         auto one = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             const double a = rl(S.q[si], i & 63);
@@ -900,7 +799,7 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
                 for (int s = 0; s <= si; ++s) S.z[s] += a * ((s < si || lane + kW * s <= i + r) ? m[r][s] : 0.0);
             }
         };
-        for_pos4n<kPS>(rows_blockwise, p, four, one);
+        for_pos4n<kPS>(kRows2D, p, four, one);
     }
 }
 
