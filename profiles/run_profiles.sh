@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 case $part in
   kt)
     python3 bench.py > $out/bench.json 2> $out/bench.err
-    rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-host-mode --no-pipelined > $out/kt.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-host-mode --no-pipelined --no-noise-sweep > $out/kt.log 2>&1
     ;;
   cf) bash profiles/pmc_curvefit.sh $out/pmc_cf ;;
   nnls) bash profiles/pmc_nnls.sh $out/pmc_nnls ;;

@@ -37,7 +37,7 @@ def test_noise_sweep_and_nnls_spread_sit_in_the_first_2000_bytes():
     """ The data dependence of both rates travels with them: noise_sweep (c3 / c4 voxels/s at sigma 0 / 1 /
     5 %) and the min / median of the three NNLS passes follow the scalars, inside what a 2 000-byte reader keeps."""
     raw = _committed_line()
-    raw["noise_sweep"] = {"sigma": [0.0, 0.01, 0.05], "voxels": 1 << 20, "c3_voxels_per_s": [160.1e6, 113.2e6, 75.3e6],
+    raw["noise_sweep"] = {"sigma": [0.0, 0.01, 0.05], "c3_voxels": 1 << 22, "c4_voxels": 1 << 20, "c3_voxels_per_s": [160.1e6, 113.2e6, 75.3e6],
                           "c4_voxels_per_s": [4.7e6, 9.1e6, 14.6e6]}
     raw["secondary"].update(ms_per_step_min=455.1, ms_per_step_median=456.2)
     line = json.dumps(bench.finalize(raw))
@@ -49,7 +49,7 @@ def test_noise_sweep_and_nnls_spread_sit_in_the_first_2000_bytes():
     keys = list(d.keys())
     assert keys.index("noise_sweep") == len(bench.HEAD_KEYS) + len(bench.SCALAR_KEYS)
     assert keys.index("roofline") > keys.index("nnls_ms_per_step_median")
-    assert tuple(bench.NOISE_SWEEP_SIGMAS) == (0.0, 0.01, 0.05) and bench.NOISE_SWEEP_VOXELS == 1 << 20
+    assert tuple(bench.NOISE_SWEEP_SIGMAS) == (0.0, 0.01, 0.05) and bench.NOISE_SWEEP_VOXELS == 1 << 20 and bench.NOISE_SWEEP_VOXELS_C3 == 1 << 22
 
 
 def test_contract_keys_come_first_and_prose_comes_last():
