@@ -23,8 +23,7 @@ constexpr int kPadBin = kNnlsMaxBins;  // bin of the padding positions: column 2
 constexpr int kScr = kMaxPos / 2 + kXbuf + 32;
 constexpr int kLdsM = PNX_BLK_LDS_ROWS;     // rows of M that live in LDS (whole block rows): what every voxel uses all the time
 constexpr int kLdsMDoubles = (kLdsM / 8 + 1) * (32 * (kLdsM / 8));  // moff(kLdsM)
-constexpr int kMRows = 32 * (kMaxPos / 8) * (kMaxPos / 8 + 1) + 64;   // doubles of M per wave: moff(kMaxPos) = 32 I (I + 1) at I = kMaxPos / 8, plus the overrun of a 64-lane row read
-constexpr int kMSlab = kMRows + kNnlsMaxBins;  // ... and behind them A^T y of the wave's current voxel by bin (the Gram-form dual of small passive sets reads it back)
+constexpr int kMSlab = 32 * (kMaxPos / 8) * (kMaxPos / 8 + 1) + 64;   // doubles of M per wave: moff(kMaxPos) = 32 I (I + 1) at I = kMaxPos / 8, plus the overrun of a 64-lane row read
 typedef int __attribute__((may_alias)) lds_int;
 
 struct BlkArgs {
@@ -73,7 +72,7 @@ __host__ __device__ constexpr int moff(int i) {
     return (I + 1) * (32 * I + 8 * a);
 }
 
-static_assert(kMRows >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
+static_assert(kMSlab >= moff(kMaxPos) + kW, "slab of M too small for kMaxPos rows");
 static_assert(kLdsMDoubles == moff(kLdsM) && kLdsM % 8 == 0, "LDS part of M: whole block rows");
 
 // M of one wave: rows < kLdsM in LDS, the others in the wave's global slab (same offsets moff(i) + k in both).  A row index
@@ -455,7 +454,7 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
 // w = A^T y - G[:, P] x_P: p rows of G (2 KB each, out of L2: their addresses are known when the iteration starts, so all of a
 // batch are in flight together) instead of the 64 KB basis out of LDS plus p column gathers -- at p <= kGramP that is fewer bytes,
 // a fifth of the vector instructions and one or two round trips instead of eight.  A^T y is this voxel's dual at p = 0 (the residual
-// form with x = 0), kept behind the wave's rows of M in its global slab (2 KB, L2; eight registers there cost scratch elsewhere).  Same quantity in another summation order; the factor M already comes from the same G.
+// form with x = 0), kept in registers.  Same quantity in another summation order; the factor M already comes from the same G.
 #ifndef PNX_BLK_GRAMP
 #define PNX_BLK_GRAMP 16  // measured 12 / 16 / 20 / 24 / 32: 8.92 / 9.01 / 9.02 / 9.03 / 8.59 M voxels/s (0: 8.52; profiles/r05_nnls_experiments.md, section 3)
 #endif
@@ -467,11 +466,12 @@ __device__ __forceinline__ void stage_ps(const double *xbuf, lds_int *ps, int p,
     ps[lane] = (int)lds_addr(xbuf + 2) + 8 * (lane < p ? pidx[0] : kPadBin);
     lds_order();
 }
-__device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, int lane, const glb_double *aty, const VoxState &S, double (&w)[kSlots]) {
+__device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, int lane, const double (&w0)[kSlots], const VoxState &S, double (&w)[kSlots]) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     stage_ps(xbuf, ps, p, lane, S.pidx);
     const glb_double *gl = (const glb_double *)kargs()->G + 2 * lane;
-    const dbl2v a01 = *reinterpret_cast<glb_cdbl2v *>(aty + 2 * lane), a23 = *reinterpret_cast<glb_cdbl2v *>(aty + 128 + 2 * lane);
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) w[s] = w0[s];
     dbl2v ga[4][2], gb[4][2];
     auto load4 = [&](int k, dbl2v (&g)[4][2]) {
 #pragma unroll
@@ -494,10 +494,6 @@ __device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, 
         }
     };
     load4(0, ga);
-    w[0] = a01.x;  // A^T y of this voxel: written by this wave at p = 0, long landed (its own stores and loads stay in order)
-    w[1] = a01.y;
-    w[2] = a23.x;
-    w[3] = a23.y;
     for (int k = 0; k < p; k += 8) {
         if (k + 4 < p) load4(k + 4, gb);
         use4(k, ga);
@@ -865,6 +861,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
         S.nrej = 0;
         int iteration = 0, status = finite ? 1 : -2;
         double w[kSlots];
+        double w0[kSlots] = {0, 0, 0, 0};  // A^T y of this voxel (its dual at p = 0), for the Gram-form dual of small passive sets
         STAMP(0);
         COUNT(0, 1);
 
@@ -891,13 +888,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                 const int mrows = (K->n_meas + 7) & ~7;
 #endif
                 if (kGramP > 0 && S.p > 0 && S.p <= kGramP)
-                    dual_gram_form(xbuf, ps, ld, M.g + kMRows, S, w);
+                    dual_gram_form(xbuf, ps, ld, w0, S, w);
                 else {
                     dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, mrows, ld, yreg, S, w);
-                    if (kGramP > 0 && S.p == 0) {  // A^T y of this voxel (the residual form with x = 0), kept behind the wave's rows of M
-                        typedef __attribute__((address_space(1))) dbl2v glb_dbl2v;
-                        *reinterpret_cast<glb_dbl2v *>(M.g + kMRows + 2 * ld) = dbl2v{w[0], w[1]};
-                        *reinterpret_cast<glb_dbl2v *>(M.g + kMRows + 128 + 2 * ld) = dbl2v{w[2], w[3]};
+                    if (kGramP > 0 && S.p == 0) {
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s) w0[s] = w[s];
                     }
                 }
 #pragma unroll
