@@ -368,10 +368,14 @@ __device__ __forceinline__ double bx_gather(const double *Bl, const double *xbuf
 // rows >= n_meas of the LDS basis are zero: the product stops at `mrows` = n_meas rounded up to the eight rows of a loop step
 typedef double dbl2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const dbl2v glb_cdbl2v;
+#ifndef PNX_BLK_DIET
+#define PNX_BLK_DIET 1  // round 5, instruction diet of the dual (0: as before; A/B builds)
+#endif
+// `between` runs behind the first eight row reads and leaves in `start` what the sums start from (the negated regulariser term of the
+// dual: four subtractions behind the product become none)
 template <class F>
-__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int mrows, int lane, double (&out)[kSlots], F &&between) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) out[s] = 0;
+__device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, int mrows, int lane, double (&out)[kSlots], F &&between,
+                                           const double (&start)[kSlots]) {
     const double *col = Bl + 2 * lane;
     double2 c0[4], c1[4], d0[4], d1[4];
 #pragma unroll
@@ -380,6 +384,8 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
         c1[r] = *reinterpret_cast<const double2 *>(col + r * kBStride + 128);
     }
     between();
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) out[s] = PNX_BLK_DIET ? -start[s] : 0.0;
 #pragma unroll 1
     for (int m = 0; m < mrows; m += 8) {
         const double *nx = col + (m + 4) * kBStride;
@@ -444,10 +450,13 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
     const Win ul = load_win(lo), uh = load_win(hi);
     lds_order();
     double u[kSlots];
-    bt_times_h(Bl, rb, mrows, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); });  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    bt_times_h(Bl, rb, mrows, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); }, u);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
     lds_order();
+    if (!PNX_BLK_DIET) {
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) w[s] -= u[s];  // (the caller masks the passive bins)
+        for (int s = 0; s < kSlots; ++s) w[s] -= u[s];
+    }
+    // (the caller masks the passive bins)
 }
 
 // ---- round 5: the dual of a SMALL passive set in Gram form ---------------------------------------------------------
@@ -896,9 +905,16 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                         for (int s = 0; s < kSlots; ++s) w0[s] = w[s];
                     }
                 }
+                // passive (and rejected, and non-existent) bins leave the arg-max: their dual becomes a huge negative number -- the HIGH word
+                // alone is replaced (0xffe00000: -8.99e307 or below whatever the low word holds; one select per bin instead of two for -inf)
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s)
-                    if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s])) w[s] = -INFINITY;
+                for (int s = 0; s < kSlots; ++s) {
+                    if (PNX_BLK_DIET) {
+                        const int hi = __builtin_amdgcn_inverse_ballot_w64(S.inP[s]) ? (int)0xffe00000 : __double2hiint(w[s]);
+                        w[s] = __hiloint2double(hi, __double2loint(w[s]));
+                    } else if (__builtin_amdgcn_inverse_ballot_w64(S.inP[s]))
+                        w[s] = -INFINITY;
+                }
             }
             STAMP(1);
 
