@@ -878,9 +878,14 @@ int nnls_shared_slabs_get(int device, size_t blk4_bytes, size_t gram_bytes, doub
         S.blk4 = S.gram = nullptr;
     }
     if (!S.blk4) {
-        PNX_HIPN(hipMalloc(&S.blk4, blk4_bytes));
-        PNX_HIPN(hipMemset(S.blk4, 0, blk4_bytes));  // the block sweeps read whole blocks, also rows nobody has written yet: finite
-        PNX_HIPN(hipMalloc(&S.gram, gram_bytes));
+        hipError_t e = hipMalloc(&S.blk4, blk4_bytes);
+        if (e == hipSuccess) e = hipMemset(S.blk4, 0, blk4_bytes);  // the block sweeps read whole blocks, also rows nobody has written yet: finite
+        if (e == hipSuccess) e = hipMalloc(&S.gram, gram_bytes);
+        if (e != hipSuccess) {  // all or nothing: a half-made set must not be handed to the next plan
+            if (S.blk4) (void)hipFree(S.blk4);
+            S.blk4 = S.gram = nullptr;
+            return set_error(PNX_ERR_NOMEM, "shared NNLS slabs (%zu + %zu bytes) on device %d: %s", blk4_bytes, gram_bytes, device, hipGetErrorString(e));
+        }
         S.blk4_bytes = blk4_bytes;
         S.gram_bytes = gram_bytes;
         if (!S.last) PNX_HIPN(hipEventCreateWithFlags(&S.last, hipEventDisableTiming));

@@ -182,6 +182,14 @@ static int blk_launch(const BlkCall &C, int64_t off, int64_t c, long long vox_ba
     a.n_reg = P->n_reg;
     a.max_iter = C.max_iter;
     for (int k = 0; k < 5; ++k) a.rc[k] = P->rc[k];
+    {  // R^T R of a tridiagonal Toeplitz R (rows a_-1, a_0, a_1 = rc[1 .. 3]) as one stencil, and the two end corrections (see dual_residual_form)
+        const double am = P->rc[1], a0 = P->rc[2], ap = P->rc[3];
+        a.rg[0] = am * am + a0 * a0 + ap * ap;
+        a.rg[1] = am * a0 + a0 * ap;
+        a.rg[2] = am * ap;
+        a.rg[3] = ap * ap;  // row -1 would have added a_1^2 x_0 to bin 0
+        a.rg[4] = am * am;  // row n would have added a_-1^2 x_{n-1} to bin n - 1
+    }
     a.rhb = P->rhb;
     a.test_rej_k = a.test_rej_n = 0;
     if (const char *t = V::max_pos == 128 ? dev_getenv("PNX_NNLS_TEST_REJECT") : nullptr) {  // the hand-over target runs without the hook (as the oracle's restatement of the hand-over does)

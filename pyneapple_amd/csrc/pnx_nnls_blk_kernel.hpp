@@ -42,6 +42,8 @@ struct BlkArgs {
     long long n_vox;
     int n_meas, n_bins, n_reg, max_iter;
     double rc[5];  // banded Toeplitz regulariser: R[i][j] = rc[j - i + 2] (mu included)
+    double rg[5];  // half bandwidth 1 only: R^T R as ONE stencil -- (R^T R)[j][j +- e] = rg[e] (e = 0, 1, 2) away from the ends; rg[3] = rc[3]^2 and
+                   // rg[4] = rc[1]^2 are what the rows R does not have (-1 and n) would have added to bins 0 and n - 1
     int rhb;       // half bandwidth, 1 or 2
     int test_rej_k, test_rej_n;  // test hook (PNX_NNLS_TEST_REJECT=k,n): with p % k == k - 1 the first n candidates of an outer iteration are rejected unseen
     const int32_t *route;  // non-null: the launch only runs while *route == route_want (the pilot of the call chose this kernel)
@@ -428,6 +430,23 @@ __device__ __forceinline__ void bt_times_h(const double *Bl, const double *v, in
 }
 // w = B^T (y - B_P x_P) - R^T (R x), all out of LDS.  LDS round trips in sequence: bins of the first positions -> column
 // gathers (one per 16 positions) -> B^T r; the stencil of R rides on the first gathers, the one of R^T on the first row reads.
+#ifndef PNX_BLK_RTR
+#define PNX_BLK_RTR 1  // half bandwidth 1 (orders 1 and 2): R^T (R x) as one five-point stencil of x (0: two three-point passes through LDS; A/B builds)
+#endif
+// the pair of bins at the centre of w: sum_e g[|e|] x[j + e], e = -2 .. 2
+__device__ __forceinline__ void rtr_eval(const Win &w, double g0, double g1, double g2, double &o0, double &o1) {
+    double a = g2 * w.lo.x, b = g2 * w.lo.y;
+    a = fma(g1, w.lo.y, a);
+    b = fma(g1, w.mid.x, b);
+    a = fma(g0, w.mid.x, a);
+    b = fma(g0, w.mid.y, b);
+    a = fma(g1, w.mid.y, a);
+    b = fma(g1, w.hi.x, b);
+    a = fma(g2, w.hi.x, a);
+    b = fma(g2, w.hi.y, b);
+    o0 = a;
+    o1 = b;
+}
 __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbuf, lds_int *ps, double *rb, const double (&rc)[5], int hb,
                                                    int n, int mrows, int lane, double yreg, const VoxState &S, double (&w)[kSlots]) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
@@ -435,22 +454,44 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
     stage_bins(xbuf, ps, p, lane, S.x, S.pidx);
     double *lo = xbuf + 2 + 2 * lane, *hi = lo + 128;
     const Win wl = load_win(lo), wh = load_win(hi);
-    double t[kSlots];
-    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() { band_eval4<false>(hb, wl, wh, rc, t); });
+    // Half bandwidth 1 (orders 1 and 2): (R^T R x)_j = rg[2] (x_{j-2} + x_{j+2}) + rg[1] (x_{j-1} + x_{j+1}) + rg[0] x_j, minus what the rows
+    // -1 and n -- which R does not have -- would have added to the bins 0 and n - 1 (x is zero outside [0, n)): one stencil of x, no
+    // second pass, no round trip of t through LDS.  Half bandwidth 2 (order 3): t = R x by bin through xbuf, then R^T t.
+    const bool merged = PNX_BLK_RTR && hb == 1;  // wave uniform
+    double t[kSlots], u[kSlots];
+    const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() {
+        if (merged) {
+            KArgs *K = kargs();
+            const double g0 = K->rg[0], g1 = K->rg[1], g2 = K->rg[2];
+            rtr_eval(wl, g0, g1, g2, u[0], u[1]);
+            rtr_eval(wh, g0, g1, g2, u[2], u[3]);
+            if (lane == 0) u[0] = fma(-K->rg[3], wl.mid.x, u[0]);  // bin 0
+            const int jl = n - 1;                                   // bin n - 1: slot and lane are wave uniform
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s)
+                if (s == slot_of_bin(jl) && lane == lane_of_bin(jl)) u[s] = fma(-K->rg[4], s == 0 ? wl.mid.x : (s == 1 ? wl.mid.y : (s == 2 ? wh.mid.x : wh.mid.y)), u[s]);
+        } else
+            band_eval4<false>(hb, wl, wh, rc, t);
+    });
     lds_order();
     if (lane < kBMeas) rb[lane] = yreg - bx;
-    // t by bin through xbuf: every gather of x has been issued, and the LDS executes a wave's instructions in order
-    *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
-    *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
+    Win ul, uh;
+    if (!merged) {
+        // t by bin through xbuf: every gather of x has been issued, and the LDS executes a wave's instructions in order
+        *reinterpret_cast<double2 *>(lo) = double2{t[0], t[1]};
+        *reinterpret_cast<double2 *>(hi) = double2{t[2], t[3]};
+        lds_order();
+        // rows >= n of R do not exist: x is zero there, so only t_n and t_{n + 1} can be non-zero -- two stores instead of a
+        // select on every lane's four values
+        if (lane < 2) xbuf[2 + n + lane] = 0.0;
+        lds_order();
+        ul = load_win(lo);
+        uh = load_win(hi);
+    }
     lds_order();
-    // rows >= n of R do not exist: x is zero there, so only t_n and t_{n + 1} can be non-zero -- two stores instead of a
-    // select on every lane's four values
-    if (lane < 2) xbuf[2 + n + lane] = 0.0;
-    lds_order();
-    const Win ul = load_win(lo), uh = load_win(hi);
-    lds_order();
-    double u[kSlots];
-    bt_times_h(Bl, rb, mrows, lane, w, [&]() { band_eval4<true>(hb, ul, uh, rc, u); }, u);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    bt_times_h(Bl, rb, mrows, lane, w, [&]() {
+        if (!merged) band_eval4<true>(hb, ul, uh, rc, u);  // (R^T t)_j = sum_d c[d + 2] t_{j - d}
+    }, u);
     lds_order();
     if (!PNX_BLK_DIET) {
 #pragma unroll
