@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the meeting points (-DPNX_BLK_KILLTEST=k) exist in the sources of commit f09b818 only (removed after the measurement);
+# the variants were built with PNX_VARIANT=kt1 PNX_NNLS_FLAGS=-DPNX_BLK_KILLTEST=1 python -m pyneapple_amd._build (and so on).
 # Round 5, VERDICT item 1(a): what lock-step costs the NNLS block kernel.  Each variant is the product's blk2 kernel with meeting
 # points added (arithmetic untouched): kt1 = one s_barrier per outer iteration (all 12 waves of the CU), kt2 = two; kt3gG = one
 # meeting point of G waves through an LDS counter, kt4g4 = two of four waves.

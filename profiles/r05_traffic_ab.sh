@@ -1,3 +1,7 @@
+#!/bin/bash
+# Round 5: traffic behind the L2 of the NNLS block kernel with A^T y in the wave's slab (the product of commit dbe6f87) against
+# A^T y in registers (libpnx_hip.w0reg.so = the kernel header of commit 7df86ff, today's product): FETCH_SIZE / WRITE_SIZE in
+# separate passes, `bench.py --workload nnls`.  r05_nnls_experiments.md section 9.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="bench.py --workload nnls --steps 1 --warmup 1 --no-cpu-baseline --no-host-mode"
