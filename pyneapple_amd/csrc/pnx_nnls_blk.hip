@@ -55,6 +55,7 @@
 // those run on the residual-form dual too (32 rows of B out of LDS per outer iteration) instead of the Gram form's p rows of G.
 #define PNX_BLK_NS blk2
 #define PNX_BLK_KERNEL nnls_blk_kernel
+#define PNX_BLK_KERNEL_HOOK nnls_blk_hook_kernel
 #define PNX_BLK_PS 2
 #define PNX_BLK_ROWS2D 48
 #ifndef PNX_BLK_WAVES
@@ -101,6 +102,7 @@ bool nnls_blk_applicable(const NnlsPlanData *P) {
 // slabs are the device's shared set, pnx_nnls.hpp)
 template <class V> static int blk_variant_init(const NnlsPlanData *P, int *groups, double **slab) {
     PNX_HIPB(hipFuncSetAttribute(V::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds_bytes()));
+    if (V::kernel_hook()) PNX_HIPB(hipFuncSetAttribute(V::kernel_hook(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds_bytes()));
     int occ = 0;
     PNX_HIPB(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, V::kernel(), V::waves * kW, V::lds_bytes()));
     if (occ < 1) return set_error(PNX_ERR_HIP, "nnls block kernel does not fit on a CU");

@@ -266,6 +266,17 @@ struct VoxState {
     int p;
 };
 
+// bin j joins / leaves the passive flags: ONE of the four masks changes, found by two scalar branches (a select per mask costs 22 scalar
+// instructions, and a scalar instruction costs what a vector instruction costs: profiles/r05_nnls_experiments.md section 15)
+__device__ __forceinline__ void set_passive(VoxState &S, int j) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull;
+}
+__device__ __forceinline__ void clear_passive(VoxState &S, int j) {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) S.inP[s] &= ~((s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull);
+}
+
 // ---- round 4: the dual with its LDS round trips overlapped ---------------------------------------------------
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 __device__ __forceinline__ unsigned lds_addr(const double *q) { return (unsigned)(size_t)q; }  // the LDS byte address is the low half of the flat one
@@ -509,47 +520,62 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
 #define PNX_BLK_GRAMP 16  // measured 12 / 16 / 20 / 24 / 32: 8.92 / 9.01 / 9.02 / 9.03 / 8.59 M voxels/s (0: 8.52; profiles/r05_nnls_experiments.md, section 3)
 #endif
 constexpr int kGramP = PNX_BLK_GRAMP;
-static_assert(kGramP >= 0 && kGramP < kW, "the Gram-form dual reads positions of the first register slot only");
+static_assert(kGramP >= 0 && kGramP < kW && kGramP % 4 == 0, "the Gram-form dual reads positions of the first register slot only, in batches of four");
 // the bins by position into ps (what stage_bins leaves for the append's prefetch), padded with kPadBin
 __device__ __forceinline__ void stage_ps(const double *xbuf, lds_int *ps, int p, int lane, const int (&pidx)[kPS]) {
     lds_order();
     ps[lane] = (int)lds_addr(xbuf + 2) + 8 * (lane < p ? pidx[0] : kPadBin);
     lds_order();
 }
+// Rows K .. K + 3 of the batch: the bins come out of lane K + u of pidx (v_readlane with a constant lane), the row address is ONE vector
+// add on top of the kernel argument (scalar base + 32-bit lane offset), and positions >= p need no select: their x is zero (the removal
+// shifts zeros in) and their stale bins are rows of G like any other.
+typedef __attribute__((address_space(1))) const char glb_cchar;
+template <int K> __device__ __forceinline__ void gram_load4(glb_cchar *G, unsigned lane16, const VoxState &S, dbl2v (&g)[4][2]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned j = (unsigned)__builtin_amdgcn_readlane(S.pidx[0], K + u);
+        glb_cchar *row = G + (lane16 + (j << 11));  // row j of G, this lane's pair of bins
+        g[u][0] = *reinterpret_cast<glb_cdbl2v *>(row);
+        g[u][1] = *reinterpret_cast<glb_cdbl2v *>(row + 1024);
+    }
+}
+template <int K> __device__ __forceinline__ void gram_use4(const dbl2v (&g)[4][2], const VoxState &S, double (&w)[kSlots]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double xk = -rl(S.x[0], K + u);
+        w[0] = fma(xk, g[u][0].x, w[0]);
+        w[1] = fma(xk, g[u][0].y, w[1]);
+        w[2] = fma(xk, g[u][1].x, w[2]);
+        w[3] = fma(xk, g[u][1].y, w[3]);
+    }
+}
+// rows K .. K + 3 are on their way in `cur` (p > K): the next four are requested before these are used.  Unrolled over the batches (the
+// chain is at most kGramP / 4 long): every batch has its own registers -- the loop it replaces swapped its two buffers by copying
+// them, 16 moves per batch -- and every lane index is a constant.
+template <int K>
+__device__ __forceinline__ void gram_chain(glb_cchar *G, unsigned lane16, int p, const VoxState &S, const dbl2v (&cur)[4][2], double (&w)[kSlots]) {
+    if constexpr (K + 4 < kGramP) {
+        if (p > K + 4) {
+            dbl2v nxt[4][2];
+            gram_load4<K + 4>(G, lane16, S, nxt);
+            gram_use4<K>(cur, S, w);
+            gram_chain<K + 4>(G, lane16, p, S, nxt, w);
+            return;
+        }
+    }
+    gram_use4<K>(cur, S, w);
+}
 __device__ __forceinline__ void dual_gram_form(const double *xbuf, lds_int *ps, int lane, const double (&w0)[kSlots], const VoxState &S, double (&w)[kSlots]) {
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     stage_ps(xbuf, ps, p, lane, S.pidx);
-    const glb_double *gl = (const glb_double *)kargs()->G + 2 * lane;
+    glb_cchar *G = (glb_cchar *)kargs()->G;
+    const unsigned lane16 = 16u * (unsigned)lane;
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) w[s] = w0[s];
-    dbl2v ga[4][2], gb[4][2];
-    auto load4 = [&](int k, dbl2v (&g)[4][2]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = k + u < p ? k + u : 0;  // beyond the passive set: any valid row (its x counts as zero)
-            const int j = __builtin_amdgcn_readlane(S.pidx[0], kk);
-            const glb_double *row = gl + (size_t)j * kNnlsMaxBins;
-            g[u][0] = *reinterpret_cast<glb_cdbl2v *>(row);
-            g[u][1] = *reinterpret_cast<glb_cdbl2v *>(row + 128);
-        }
-    };
-    auto use4 = [&](int k, const dbl2v (&g)[4][2]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double xk = k + u < p ? -rl(S.x[0], (k + u) & 63) : 0.0;
-            w[0] = fma(xk, g[u][0].x, w[0]);
-            w[1] = fma(xk, g[u][0].y, w[1]);
-            w[2] = fma(xk, g[u][1].x, w[2]);
-            w[3] = fma(xk, g[u][1].y, w[3]);
-        }
-    };
-    load4(0, ga);
-    for (int k = 0; k < p; k += 8) {
-        if (k + 4 < p) load4(k + 4, gb);
-        use4(k, ga);
-        if (k + 8 < p) load4(k + 8, ga);
-        if (k + 4 < p) use4(k + 4, gb);
-    }
+    dbl2v first[4][2];
+    gram_load4<0>(G, lane16, S, first);
+    gram_chain<0>(G, lane16, p, S, first, w);
 }
 
 // blocks (I, K), K <= I < NI, of this wave's M: every load is issued before the first use
@@ -586,11 +612,44 @@ __device__ __forceinline__ void append_prefetch(const lds_int *ps, int lb, unsig
 #pragma unroll
     for (int K = 0; K < NI; ++K) goff[K] = (unsigned)(ps[8 * K + lb] - ps_base);  // ps holds LDS addresses of x by bin
 }
+// What an outer iteration's candidate step computes before anything changes: the candidate bin, the independence test, and the new row
+// of M up to its scale.  The voxel state is only READ here -- the three instantiations (by the number of block rows in use) merge in
+// a handful of fresh values, not in a copy of the state: returning "rejected / accepted" from a function that also updates the state
+// cost every outer iteration ~25 register moves (the unchanged parts of the state copied to where the changed ones were computed).
+struct AppendOut {
+    double a1[kPS];  // l^T M by position (exactly +0 at and behind position p)
+    double ilam, qn;
+    int jmax;
+    bool ok;
+};
+// lowest bin that attains the maximum `best` of the masked duals: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1)).
+// s_ff1 answers -1 for an empty mask, so as UNSIGNED numbers the four candidates order themselves, an empty one last: three s_min_u32,
+// no select.  Some lane holds the maximum (best > 0 is one of the w), so the result is a bin; the & 255 only keeps a row index of G in
+// range whatever happens.
+__device__ __forceinline__ unsigned ff1(unsigned long long m) {  // the instruction as it is: __ffsll() - 1 puts a compare and a select behind it for the empty mask
+    int r;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+    return (unsigned)r;
+}
+__device__ __forceinline__ int argmax_bin(const double (&w)[kSlots], double best) {
+    const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
+    const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
+    const unsigned b0 = ff1(m0) << 1;
+    const unsigned b1 = (ff1(m1) << 1) | 1u;
+    const unsigned b2 = (ff1(m2) << 1) | 128u;
+    const unsigned b3 = (ff1(m3) << 1) | 129u;
+    unsigned lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
+    asm("" : "+s"(lo), "+s"(hi));  // scalar registers: left alone the compiler folds the three minima into one v_min3_u32, and the bin -- a row address of G -- lives in a vector register from then on
+    return (int)((lo < hi ? lo : hi) & 255u);
+}
 template <int NI>
-__device__ __forceinline__ bool try_append(const double *G, const MRef &M, const lds_int *ps, int lane, int la, int lb, int jmax,
-                                           double wj, VoxState &S
-                                           , const unsigned (&goff)[NI]
-) {
+__device__ __forceinline__ void append_prepare(const double *G, const MRef &M, const lds_int *ps, int lane, const double (&w)[kSlots], double wj,
+                                               const VoxState &S, AppendOut &A) {
+    const int la = lane >> 3, lb = lane & 7;
+    unsigned goff[NI];
+    append_prefetch<NI>(ps, lb, goff);  // its LDS round trip hides behind the bit scans
+    const int jmax = argmax_bin(w, wj);
+    A.jmax = jmax;
     const int p = __builtin_amdgcn_readfirstlane(S.p);
     const double *grow = G + (size_t)jmax * kNnlsMaxBins;
     double blk[NI][NI];
@@ -698,94 +757,53 @@ __device__ __forceinline__ bool try_append(const double *G, const MRef &M, const
     // ztest = qn / lam with qn = (a_j^T residual) / lam: the residual-form dual w_j IS a_j^T residual
     const double qn = wj * ilam;
     ok = ok && qn > 0;
-    if (!ok) return false;
 #ifdef PNX_NNLS_TRACE
     if (lane == 0 && blockIdx.x == 0 && threadIdx.x < 64) printf("A p=%d j=%d lam=%.17g qn=%.17g\n", p, jmax, lam, qn);
 #endif
+    A.ok = ok;
+    A.ilam = ilam;
+    A.qn = qn;
     // column sums over a, delivered in position order (position 8 la + lb is column block K = la)
     a1[0] += reduce_scatter_a<NI>(rK, la);
-    // the new row by position: -(l^T M) / lam in front of position p (beyond it l^T M is zero: those columns of M are), 1 / lam
-    // at p.  The masks are scalar (p is wave uniform): no vector compare, and the second register slot only where it is in use.
-    {
-        const int pbase = moff(p);
-        const int width = 8 * ((p >> 3) + 1);
-        const int sp = p >> 6;
-        const unsigned long long bit = 1ull << (p & 63);
 #pragma unroll
-        for (int s = 0; s < kPS; ++s) {
-            if (kW * s <= p) {  // wave uniform
-                const unsigned long long at_p = s == sp ? bit : 0ull;
-                double rowv = -a1[s] * ilam;
-                if (__builtin_amdgcn_inverse_ballot_w64(at_p)) {
-                    rowv = ilam;
-                    S.x[s] = 0.0;
-                    S.q[s] = qn;
-                    S.pidx[s] = jmax;
-                }
-                if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
-                S.z[s] = fma(rowv, qn, S.x[s]);  // the rank-one update of the solution: z = x + row * qn (x_p = 0)
+    for (int s = 0; s < kPS; ++s) A.a1[s] = a1[s];
+}
+// The column enters: new row of M = [-(l^T M) / lam, 1 / lam], z = x + row * qn (x == M^T q whenever a column enters), q_p = qn.
+// l^T M is exactly +0 at p and behind it (M has no such column yet: those entries are zero), so a -1 written into lane p of it -- one
+// v_writelane of the high word -- makes the whole row ONE multiply; q and the bin of the new position are lane writes too (no EXEC
+// mask, no copy of the state for the lanes that keep theirs).  x is zero at p already: positions >= p hold zeros (a removal shifts
+// them in).
+__device__ __forceinline__ void append_commit(const MRef &M, int lane, AppendOut &A, VoxState &S) {
+    const int p = __builtin_amdgcn_readfirstlane(S.p);
+    const int pbase = moff(p);
+    const int width = 8 * ((p >> 3) + 1);
+    const int sp = p >> 6, pl = p & 63;
+    const double qs = uni(A.qn);
+#pragma unroll
+    for (int s = 0; s < kPS; ++s) {
+        if (kW * s <= p) {  // wave uniform
+            if (s == sp) {  // wave uniform
+                A.a1[s] = __hiloint2double(pnx_writelane((int)0xBFF00000, pl, __double2hiint(A.a1[s])), __double2loint(A.a1[s]));
+                S.q[s] = __hiloint2double(pnx_writelane(__double2hiint(qs), pl, __double2hiint(S.q[s])),
+                                          pnx_writelane(__double2loint(qs), pl, __double2loint(S.q[s])));
+                S.pidx[s] = pnx_writelane(A.jmax, pl, S.pidx[s]);
             }
+            const double rowv = -A.a1[s] * A.ilam;
+            if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
+            S.z[s] = fma(rowv, A.qn, S.x[s]);  // the rank-one update of the solution: z = x + row * qn (x_p = 0)
         }
     }
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s)
-        S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;  // scalar: jmax is wave uniform
+    set_passive(S, A.jmax);
     S.p = p + 1;
-    return true;
 }
 
 constexpr int kMaxRej = 8;  // rejected columns an outer iteration can remember (the four spare doubles behind xbuf's halo)
-// The candidate step of an outer iteration: largest positive dual (ties: lowest bin), then the append.  Returns 0 when no dual
-// is positive (KKT satisfied), 1 when the column entered, 2 when it was rejected, 3 when it was rejected and the list is full.
 // A rejected column is what Lawson-Hanson answers with "w_j = 0, take the next largest".  It is rare (none in 28 000 outer
 // iterations of the reference workload), so it is not worth a loop around the append -- a loop keeps w[] and a copy of the
 // voxel state alive across the append and lets the compiler hoist the append's addresses in front of it: 64 bytes of scratch
 // per lane written in every outer iteration, which on this chip is HBM traffic.  Instead the column's passive flag is set for
 // the time being, its bin is remembered in LDS, and the outer loop evaluates the dual again (same state, same values; the
 // flag masks the column); the flags are taken back when a column enters.
-template <int NI>
-__device__ __forceinline__ int candidate(const double *G, const MRef &M, const lds_int *ps, lds_int *rejlist, int lc, const double (&w)[kSlots],
-                                         VoxState &S) {
-    const int la = lc >> 3, lb = lc & 7;
-    unsigned goff[NI];
-    append_prefetch<NI>(ps, lb, goff);
-    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-    if (!(best > 0)) return 0;  // KKT satisfied
-    // lowest bin that attains it: ballots and scalar bit scans (bin = 128 (s >> 1) + 2 lane + (s & 1))
-    int jmax;
-    {
-        const unsigned long long m0 = __ballot(w[0] == best), m1 = __ballot(w[1] == best);
-        const unsigned long long m2 = __ballot(w[2] == best), m3 = __ballot(w[3] == best);
-        const int b0 = m0 ? 2 * (__ffsll((unsigned long long)m0) - 1) : kNone;
-        const int b1 = m1 ? 2 * (__ffsll((unsigned long long)m1) - 1) + 1 : kNone;
-        const int b2 = m2 ? 128 + 2 * (__ffsll((unsigned long long)m2) - 1) : kNone;
-        const int b3 = m3 ? 129 + 2 * (__ffsll((unsigned long long)m3) - 1) : kNone;
-        const int lo = b0 < b1 ? b0 : b1, hi = b2 < b3 ? b2 : b3;
-        jmax = lo < hi ? lo : hi;
-    }
-    if (jmax == kNone) return 0;  // cannot happen (some lane holds the maximum); never index G with it
-    // test hook: reject valid columns, so that the bookkeeping of rejected columns runs although the reference workload never
-    // rejects one (the minimiser is unique with a regulariser: the solve must arrive at the same spectrum by another path)
-    const int tk = kargs()->test_rej_k;
-    const bool forced = tk > 0 && (__builtin_amdgcn_readfirstlane(S.p) % tk) == tk - 1 && __builtin_amdgcn_readfirstlane(S.nrej) < kargs()->test_rej_n;
-    if (!forced && try_append<NI>(G, M, ps, lc, la, lb, jmax, best, S, goff)) {
-        const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
-        for (int k = 0; k < nr; ++k) {  // the columns rejected meanwhile may be looked at again
-            const int j = __builtin_amdgcn_readfirstlane(rejlist[k]);
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s) S.inP[s] &= ~((s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull);
-        }
-        S.nrej = 0;
-        return 1;
-    }
-    const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
-    if (nr >= kMaxRej) return 3;
-    if (lc == 0) rejlist[nr] = jmax;
-    S.nrej = nr + 1;
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(jmax)) ? (1ull << lane_of_bin(jmax)) : 0ull;
-    return 2;
-}
 
 // z = M^T q
 template <int NI>
@@ -850,8 +868,9 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
 }
 
 constexpr int kBail = 2;  // internal status: the passive set wants more than kMaxPos columns, the general kernel redoes the voxel
+constexpr int kDone = 3;  // internal status: no dual is positive (KKT satisfied) -- becomes 1 behind the loop
 
-__global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {  // read through kargs()
+template <bool HOOK> __device__ __forceinline__ void blk_body() {
 #ifdef PNX_NNLS_STAMP
     unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -959,39 +978,65 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
             }
             STAMP(1);
 
-            bool accepted = false;
             {
-                if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: hand the voxel over unless it is done
-                    const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
-                    if (best > 0) status = kBail;
-                } else {
-                    const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
-                    const int lc = fresh(lane);
-                    const double *Gp = kargs()->G;
-                    lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);  // the four spare doubles behind the halo
-                    int r;
-                    if (nI <= 2)
-                        r = candidate<2>(Gp, M, ps, rejlist, lc, w, S);
-                    else if (nI <= 4)
-                        r = candidate<4>(Gp, M, ps, rejlist, lc, w, S);
-                    else if (nI <= 6 || kNIMax == 6)
-                        r = candidate<6>(Gp, M, ps, rejlist, lc, w, S);
-                    else
-                        r = candidate<kNIMax>(Gp, M, ps, rejlist, lc, w, S);
-                    r = __builtin_amdgcn_readfirstlane(r);
-                    if (r == 2) {
-                        COUNT(2, 1);
-#ifdef PNX_NNLS_STAMP
-                        if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
-#endif
-                        continue;  // a rejected column: its flag is set, the dual is evaluated again
-                    }
-                    if (r == 3) status = kBail;  // more rejections in one outer iteration than the list holds: the general kernel
-                    accepted = r == 1;
+                // largest dual: none positive = KKT satisfied, the voxel is done.  (Tested here, in front of the instantiations of the candidate
+                // step: a return value of theirs would merge the unchanged voxel state with the one an append leaves -- 15 register moves
+                // in every outer iteration for the sake of the last.)
+                const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
+                if (!(best > 0)) {
+                    status = kDone;
+                    asm volatile("" : "+s"(status));
+                    continue;
                 }
+                if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: the voxel is handed over
+                    status = kBail;
+                    asm volatile("" : "+s"(status));
+                    continue;
+                }
+                const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
+                const int lc = fresh(lane);
+                const double *Gp = kargs()->G;
+                AppendOut A;
+                if (nI <= 2)
+                    append_prepare<2>(Gp, M, ps, lc, w, best, S, A);
+                else if (nI <= 4)
+                    append_prepare<4>(Gp, M, ps, lc, w, best, S, A);
+                else if (nI <= 6 || kNIMax == 6)
+                    append_prepare<6>(Gp, M, ps, lc, w, best, S, A);
+                else
+                    append_prepare<kNIMax>(Gp, M, ps, lc, w, best, S, A);
+                bool rejected = !A.ok;
+                if (HOOK) {
+                    // test hook (instantiation HOOK only: a kernel of its own, so that the product's outer iteration carries none of it): reject
+                    // valid columns, so that the bookkeeping of rejected columns runs although the reference workload never rejects one (the
+                    // minimiser is unique with a regulariser: the solve must arrive at the same spectrum by another path)
+                    const int tk = kargs()->test_rej_k;
+                    rejected = rejected || (tk > 0 && (__builtin_amdgcn_readfirstlane(S.p) % tk) == tk - 1 && __builtin_amdgcn_readfirstlane(S.nrej) < kargs()->test_rej_n);
+                }
+                lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);  // the four spare doubles behind the halo
+                if (rejected) {  // its passive flag is set for now and the dual is evaluated again (same state, same values; the flag masks the column)
+                    COUNT(2, 1);
+#ifdef PNX_NNLS_STAMP
+                    if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
+#endif
+                    const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
+                    if (nr >= kMaxRej) {  // more rejections in one outer iteration than the list holds: the general kernel
+                        status = kBail;
+                        asm volatile("" : "+s"(status));
+                        continue;
+                    }
+                    if (lc == 0) rejlist[nr] = A.jmax;
+                    S.nrej = nr + 1;
+                    set_passive(S, A.jmax);
+                    continue;
+                }
+                append_commit(M, lc, A, S);
+                const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
+                for (int k = 0; k < nr; ++k)  // the columns rejected meanwhile may be looked at again
+                    clear_passive(S, __builtin_amdgcn_readfirstlane(rejlist[k]));
+                S.nrej = 0;
             }
             STAMP(2);
-            if (!accepted) break;
             STAMP(3);
 
             // ---- inner loop: keep the passive-set solution feasible
@@ -1126,10 +1171,15 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                             constexpr int rg = decltype(RG)::value;  // 0: rows i .. i + nb in LDS, 1: all in the slab, 2: decided per row
                             double nx[nb][si + 1];
                             double2 c2[nb];
-                            int mo[nb + 1];  // moff(i) .. moff(i + nb)
-                            mo[0] = moff(i);
+                            // moff(i) .. moff(i + nb): lane r works out moff(i + r) -- six vector instructions for the batch and a v_readlane per
+                            // row instead of seven scalar instructions per row (a scalar instruction costs what a vector instruction costs)
+                            int mo[nb + 1];
+                            {
+                                const int k = i + lane, I = k >> 3;
+                                const int v = (int)(__umul24((unsigned)(I + 1), (unsigned)(k - 4 * I)) << 3);  // (I + 1) (32 I + 8 a), a = k - 8 I
 #pragma unroll
-                            for (int r = 0; r < nb; ++r) mo[r + 1] = moff(i + r + 1);  // (the recurrence moff(k + 1) = moff(k) + 8 (k / 8 + 1) measured 4 % slower: a dependent chain)
+                                for (int r = 0; r <= nb; ++r) mo[r] = __builtin_amdgcn_readlane(v, r);
+                            }
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
                                 const int nbase = mo[r + 1];
@@ -1141,24 +1191,31 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                             }
 #pragma unroll
                             for (int r = 0; r < nb; ++r) c2[r] = cf[i + r];
+                            // row i + r ends at position i + r: only its LAST register slot is masked (lanes <= i + r - 64 si), and the mask of the
+                            // next row is this one shifted by a lane -- two scalar instructions per row instead of six
+                            unsigned long long rm = lanes_le(i - kW * si);
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
                                 const double c_ = c2[r].x, s_ = c2[r].y;
                                 const int obase = mo[r];
+                                auto rot = [&](int s) {
+                                    const double outv = c_ * car[s] - s_ * nx[r][s];
+                                    // car = fma(s, car, c nx) IN PLACE (the three-operand form): the compiler takes v_fmac into the product's register
+                                    // and copies the result back, because the update sits under an EXEC mask
+                                    const double cn = c_ * nx[r][s];
+                                    asm("v_fma_f64 %0, %1, %0, %2" : "+v"(car[s]) : "v"(s_), "v"(cn));
+                                    const int oidx = obase + lane + kW * s;
+                                    if (rg == 0)
+                                        M.l[oidx] = outv;
+                                    else if (rg == 1)
+                                        M.g[CK(oidx, kMSlab, 11, i + r)] = outv;
+                                    else
+                                        M.st(i + r, oidx, outv);
+                                };
 #pragma unroll
-                                for (int s = 0; s <= si; ++s) {
-                                    if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(i + r - kW * s))) {
-                                        const double outv = c_ * car[s] - s_ * nx[r][s];
-                                        car[s] = s_ * car[s] + c_ * nx[r][s];
-                                        const int oidx = obase + lane + kW * s;
-                                        if (rg == 0)
-                                            M.l[oidx] = outv;
-                                        else if (rg == 1)
-                                            M.g[CK(oidx, kMSlab, 11, i + r)] = outv;
-                                        else
-                                            M.st(i + r, oidx, outv);
-                                    }
-                                }
+                                for (int s = 0; s < si; ++s) rot(s);
+                                if (__builtin_amdgcn_inverse_ballot_w64(rm)) rot(si);
+                                rm = (rm << 1) | 1ull;
                             }
                         };
                         const int hi = pp - 1;
@@ -1215,14 +1272,12 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
 #pragma unroll
                         for (int s = 0; s < kPS; ++s) {
                             const int i = lane + kW * s;
-                            if (i >= jj && i < pp - 1) {
+                            if (i >= jj) {  // also the positions behind the passive set: they hold zeros (x) / stale bins, and so does what moves in
                                 S.x[s] = xsh[s];
                                 S.pidx[s] = psh[s];
                             }
                         }
-#pragma unroll
-                        for (int s = 0; s < kSlots; ++s)
-                            S.inP[s] &= ~((s == slot_of_bin(bin_out)) ? (1ull << lane_of_bin(bin_out)) : 0ull);
+                        clear_passive(S, bin_out);
                     }
                     if (pp - 1 < kLdsM) {  // the vacated last row: LDS rows >= p of M stay zero (the block sweeps mask global rows only)
                         const int vbase = moff(pp - 1);
@@ -1263,6 +1318,7 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
                 STAMP(6);
             }
         }
+        if (status == kDone) status = 1;
         STAMP(7);
 
         // ---- the next voxel starts from an all-zero LDS part of M
@@ -1328,12 +1384,29 @@ __global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) {
         printf("PHIST p=0:%lld 1-4:%lld 5-8:%lld 9-12:%lld 13-16:%lld 17-24:%lld 25-32:%lld\n", cnt[8], cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14]);
 #endif
 }
+__global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL(const BlkArgs) { blk_body<false>(); }  // the arguments are read through kargs()
+#if PNX_BLK_PS == 2
+__global__ void __launch_bounds__(kBlkWaves *kW) PNX_BLK_KERNEL_HOOK(const BlkArgs) { blk_body<true>(); }  // with the test hook (tests only)
+#endif
 // what the host side needs to know about this instantiation
 struct Variant {
     typedef BlkArgs Args;
     static constexpr int waves = kBlkWaves, mslab = kMSlab, max_pos = kMaxPos;
     static const void *kernel() { return (const void *)PNX_BLK_KERNEL; }
-    static void launch(dim3 grid, size_t lds, hipStream_t stream, const BlkArgs &a) { hipLaunchKernelGGL(PNX_BLK_KERNEL, grid, dim3(kBlkWaves * kW), lds, stream, a); }
+#if PNX_BLK_PS == 2
+    static const void *kernel_hook() { return (const void *)PNX_BLK_KERNEL_HOOK; }
+#else
+    static const void *kernel_hook() { return nullptr; }  // the hand-over target runs without the hook
+#endif
+    static void launch(dim3 grid, size_t lds, hipStream_t stream, const BlkArgs &a) {
+#if PNX_BLK_PS == 2
+        if (a.test_rej_k > 0) {
+            hipLaunchKernelGGL(PNX_BLK_KERNEL_HOOK, grid, dim3(kBlkWaves * kW), lds, stream, a);
+            return;
+        }
+#endif
+        hipLaunchKernelGGL(PNX_BLK_KERNEL, grid, dim3(kBlkWaves * kW), lds, stream, a);
+    }
     static size_t lds_bytes() { return sizeof(double) * ((size_t)kBMeas * kBStride + (size_t)kBlkWaves * (kScr + kLdsMDoubles)); }
 };
 

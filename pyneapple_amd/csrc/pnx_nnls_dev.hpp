@@ -11,6 +11,8 @@ namespace pnx {
 
 constexpr int kW = 64;
 constexpr int kSlots = kNnlsMaxBins / kW;  // 4 (the wide instantiations of the Gram- and QR-form kernels: kNnlsWideBins / kW = 8)
+// v_writelane_b32 (value and lane in scalar registers): clang has no builtin of that name, the LLVM intrinsic is reached through its name
+extern "C" __device__ int pnx_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 constexpr int kNone = 1 << 30;
 
 // ---- cross-lane primitives ----------------------------------------------------------------------
