@@ -201,6 +201,8 @@ template <int NI> __device__ __forceinline__ double reduce_scatter_a(const doubl
 __device__ __forceinline__ unsigned long long lanes_le(int k) {
     return k >= 63 ? ~0ull : (k < 0 ? 0ull : ((2ull << k) - 1ull));
 }
+// the same where k >= 0 is known (a row or a passive set that exists): three scalar instructions instead of six
+__device__ __forceinline__ unsigned long long lanes_le_nn(int k) { return ~0ull >> (63 - (k < 63 ? k : 63)); }
 // position i receives the value of position i + 1, on DPP (wave_shl:1: lane l reads lane l + 1; lane 63 keeps `old` = lane 0 of
 // the next slot): two v_mov_dpp per double instead of two ds_bpermute round trips
 __device__ __forceinline__ double wshl1(double v, double last) {
@@ -292,9 +294,12 @@ __device__ __forceinline__ void stage_bins(double *xbuf, lds_int *ps, int p, int
 #pragma unroll
     for (int s = 0; s < kPS; ++s) {
         const int i = lane + kW * s;
-        if (kW * s <= p && i < kMaxPos) {  // wave uniform
-            ps[i] = (int)lds_addr(xbuf + 2) + 8 * (i < p ? pidx[s] : kPadBin);  // LDS address of x by bin: a gather of x needs no address arithmetic
-            if (i < p) xbuf[2 + pidx[s]] = x[s];
+        if (kW * s <= p) {  // wave uniform
+            // positions >= p of the slot: the padding bin -- whose x (xbuf[2 + kPadBin]) is zero and stays so, because x is zero at
+            // those positions (a removal shifts zeros in): one select, then every lane stores without a branch
+            const int bin = i < p ? pidx[s] : kPadBin;
+            ps[i] = (int)lds_addr(xbuf + 2) + 8 * bin;  // LDS address of x by bin: a gather of x needs no address arithmetic
+            xbuf[2 + bin] = x[s];
         }
     }
     lds_order();
@@ -470,17 +475,36 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
     // second pass, no round trip of t through LDS.  Half bandwidth 2 (order 3): t = R x by bin through xbuf, then R^T t.
     const bool merged = PNX_BLK_RTR && hb == 1;  // wave uniform
     double t[kSlots], u[kSlots];
+    // the stencil's coefficients are read BEFORE the gathers are issued: scalar loads share their counter with LDS, so a load behind
+    // them waits for every gather in flight (it did: the stencil was meant to ride on that round trip and ran behind it)
+    double g0 = 0, g1 = 0, g2 = 0, e0 = 0, e1 = 0;
+    if (merged) {
+        KArgs *K = kargs();
+        g0 = K->rg[0], g1 = K->rg[1], g2 = K->rg[2], e0 = K->rg[3], e1 = K->rg[4];
+    }
     const double bx = bx_gather(Bl, xbuf, ps, p, lane, [&]() {
         if (merged) {
-            KArgs *K = kargs();
-            const double g0 = K->rg[0], g1 = K->rg[1], g2 = K->rg[2];
             rtr_eval(wl, g0, g1, g2, u[0], u[1]);
             rtr_eval(wh, g0, g1, g2, u[2], u[3]);
-            if (lane == 0) u[0] = fma(-K->rg[3], wl.mid.x, u[0]);  // bin 0
-            const int jl = n - 1;                                   // bin n - 1: slot and lane are wave uniform
-#pragma unroll
-            for (int s = 0; s < kSlots; ++s)
-                if (s == slot_of_bin(jl) && lane == lane_of_bin(jl)) u[s] = fma(-K->rg[4], s == 0 ? wl.mid.x : (s == 1 ? wl.mid.y : (s == 2 ? wh.mid.x : wh.mid.y)), u[s]);
+            // the two end corrections, each on ONE lane of ONE slot: a select on the result (bin 0), and for bin n - 1 -- whose slot is wave
+            // uniform -- scalar branches to the one slot concerned (four EXEC-masked blocks with a scalar load each before)
+            const double c0 = fma(-e0, wl.mid.x, u[0]);
+            u[0] = lane == 0 ? c0 : u[0];
+            const int jl = n - 1, sl = slot_of_bin(jl);
+            const bool at = lane == lane_of_bin(jl);
+            if (sl == 3) {
+                const double c = fma(-e1, wh.mid.y, u[3]);
+                u[3] = at ? c : u[3];
+            } else if (sl == 2) {
+                const double c = fma(-e1, wh.mid.x, u[2]);
+                u[2] = at ? c : u[2];
+            } else if (sl == 1) {
+                const double c = fma(-e1, wl.mid.y, u[1]);
+                u[1] = at ? c : u[1];
+            } else {
+                const double c = fma(-e1, wl.mid.x, u[0]);
+                u[0] = at ? c : u[0];
+            }
         } else
             band_eval4<false>(hb, wl, wh, rc, t);
     });
@@ -789,7 +813,7 @@ __device__ __forceinline__ void append_commit(const MRef &M, int lane, AppendOut
                 S.pidx[s] = pnx_writelane(A.jmax, pl, S.pidx[s]);
             }
             const double rowv = -A.a1[s] * A.ilam;
-            if (__builtin_amdgcn_inverse_ballot_w64(lanes_le(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
+            if (__builtin_amdgcn_inverse_ballot_w64(lanes_le_nn(width - 1 - kW * s))) M.st(p, pbase + lane + kW * s, rowv);
             S.z[s] = fma(rowv, A.qn, S.x[s]);  // the rank-one update of the solution: z = x + row * qn (x_p = 0)
         }
     }
@@ -929,11 +953,18 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
         S.p = 0;
         S.nrej = 0;
         int iteration = 0, status = finite ? 1 : -2;
+        const int max_it = kargs()->max_iter;  // once per voxel: read in the inner loop it is a scalar load and a wait for every LDS access in flight per iteration
         double w[kSlots];
         double w0[kSlots] = {0, 0, 0, 0};  // A^T y of this voxel (its dual at p = 0), for the Gram-form dual of small passive sets
         STAMP(0);
         COUNT(0, 1);
 
+        // Two loops.  The inner one is the outer iteration of Lawson-Hanson as the reference workload runs it: dual, candidate, append, inner
+        // loop.  Its rare ways out -- KKT satisfied, no room, a rejected column -- LEAVE it with the voxel state untouched, so the state is
+        // loop carried along ONE path and updated in place.  With `continue` on those paths the loop's latch merged the unchanged state
+        // with the one an append leaves, and the compiler paid for that merge with ~30 register moves in every outer iteration.
+        int jrej = -1;  // >= 0: the column the candidate step rejected
+        for (;;) {
         while (status == 1 && S.p < n && S.p < m_total) {
             // ---- dual in residual form, all out of LDS: w = B^T (y - B_P x_P) - R^T (R x)
             COUNT(1, 1);
@@ -985,13 +1016,11 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                 const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
                 if (!(best > 0)) {
                     status = kDone;
-                    asm volatile("" : "+s"(status));
-                    continue;
+                    break;
                 }
                 if (S.p >= kMaxPos) {  // no room for another column in this kernel's registers: the voxel is handed over
                     status = kBail;
-                    asm volatile("" : "+s"(status));
-                    continue;
+                    break;
                 }
                 const int nI = (S.p >> 3) + 1;  // block rows in use, the one the new row goes to included
                 const int lc = fresh(lane);
@@ -1014,21 +1043,9 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                     rejected = rejected || (tk > 0 && (__builtin_amdgcn_readfirstlane(S.p) % tk) == tk - 1 && __builtin_amdgcn_readfirstlane(S.nrej) < kargs()->test_rej_n);
                 }
                 lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);  // the four spare doubles behind the halo
-                if (rejected) {  // its passive flag is set for now and the dual is evaluated again (same state, same values; the flag masks the column)
-                    COUNT(2, 1);
-#ifdef PNX_NNLS_STAMP
-                    if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
-#endif
-                    const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
-                    if (nr >= kMaxRej) {  // more rejections in one outer iteration than the list holds: the general kernel
-                        status = kBail;
-                        asm volatile("" : "+s"(status));
-                        continue;
-                    }
-                    if (lc == 0) rejlist[nr] = A.jmax;
-                    S.nrej = nr + 1;
-                    set_passive(S, A.jmax);
-                    continue;
+                if (rejected) {  // (the bookkeeping is behind this loop)
+                    jrej = A.jmax;
+                    break;
                 }
                 append_commit(M, lc, A, S);
                 const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
@@ -1042,7 +1059,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
             // ---- inner loop: keep the passive-set solution feasible
             for (;;) {
                 iteration += 1;
-                if (iteration == kargs()->max_iter) {
+                if (iteration == max_it) {
                     status = 0;
                     break;
                 }
@@ -1052,7 +1069,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                 unsigned long long vm[kPS], vany = 0;
 #pragma unroll
                 for (int s = 0; s < kPS; ++s) {
-                    vm[s] = p > kW * s ? (__ballot(S.z[s] <= 0) & lanes_le(p - 1 - kW * s)) : 0ull;
+                    vm[s] = p > kW * s ? (__ballot(S.z[s] <= 0) & lanes_le_nn(p - 1 - kW * s)) : 0ull;
                     vany |= vm[s];
                 }
                 if (!vany) {  // feasible: x = z (positions >= p hold nothing that is read)
@@ -1193,7 +1210,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                             for (int r = 0; r < nb; ++r) c2[r] = cf[i + r];
                             // row i + r ends at position i + r: only its LAST register slot is masked (lanes <= i + r - 64 si), and the mask of the
                             // next row is this one shifted by a lane -- two scalar instructions per row instead of six
-                            unsigned long long rm = lanes_le(i - kW * si);
+                            unsigned long long rm = lanes_le_nn(i - kW * si);
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
                                 const double c_ = c2[r].x, s_ = c2[r].y;
@@ -1294,7 +1311,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                         bad = kNone;
 #pragma unroll
                         for (int s = kPS - 1; s >= 0; --s) {
-                            const unsigned long long bs = pn > kW * s ? (__ballot(S.x[s] <= 0) & lanes_le(pn - 1 - kW * s)) : 0ull;
+                            const unsigned long long bs = pn > kW * s ? (__ballot(S.x[s] <= 0) & lanes_le_nn(pn - 1 - kW * s)) : 0ull;
                             if (bs) bad = kW * s + __ffsll(bs) - 1;
                         }
                     }
@@ -1317,6 +1334,26 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                 }
                 STAMP(6);
             }
+        }
+        if (jrej < 0) break;
+        // a rejected column: its passive flag is set for now, its bin is remembered, and the dual is evaluated again (same state, same
+        // values; the flag masks the column)
+        {
+            COUNT(2, 1);
+#ifdef PNX_NNLS_STAMP
+            if (lane == 0) atomicAdd(&g_blk_rejects, 1ULL);
+#endif
+            lds_int *rejlist = reinterpret_cast<lds_int *>(xbuf + 2 + kNnlsMaxBins + 2);
+            const int nr = __builtin_amdgcn_readfirstlane(S.nrej);
+            if (nr >= kMaxRej) {  // more rejections in one outer iteration than the list holds: the general kernel
+                status = kBail;
+                break;
+            }
+            if (lane == 0) rejlist[nr] = jrej;
+            S.nrej = nr + 1;
+            set_passive(S, jrej);
+            jrej = -1;
+        }
         }
         if (status == kDone) status = 1;
         STAMP(7);
