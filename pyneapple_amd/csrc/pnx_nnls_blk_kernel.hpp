@@ -157,6 +157,27 @@ __device__ __forceinline__ double allreduce_max(double v) {
     }
     return v;
 }
+// Largest POSITIVE value of the wave as a wave-uniform number (0 if there is none): where only that is wanted, the last two steps are
+// row broadcasts (row_bcast:15 / row_bcast:31, three instructions each) instead of the 16- and 32-lane swaps (five each), and the total is
+// read from lane 63.  A broadcast has no source for row 0 (rows 0 and 1): those lanes receive zero, which a maximum that only counts
+// when it is positive does not see.
+__device__ __forceinline__ double wave_max_pos_uni(double v) {
+    v = max1(v, dppx<0xB1>(v));
+    v = max1(v, dppx<0x4E>(v));
+    v = max1(v, dppx<0x141>(v));
+    v = max1(v, dppx<0x140>(v));  // row_mirror: every lane of a row of 16 holds the row's maximum
+    v = max1(v, dppx<0x142>(v));  // row_bcast:15: row r receives lane 15 of row r - 1
+    v = max1(v, dppx<0x143>(v));  // row_bcast:31: rows 2 and 3 receive lane 31
+    return rl(v, 63);
+}
+// sum over a = lane >> 3 of a value that does not depend on b = lane & 7, as a wave-uniform value: row_ror 8, then the two row
+// broadcasts (zero where there is no source); lane 63 ends with the same tree of additions as allreduce_a -- the same bits
+__device__ __forceinline__ double sum_a_uni(double v) {
+    v += dppx<0x128>(v);
+    v += dppx<0x142>(v);
+    v += dppx<0x143>(v);
+    return rl(v, 63);
+}
 // over b = lane & 7: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
 __device__ __forceinline__ double allreduce_b(double v) {
     v += dppx<0xB1>(v);
@@ -197,6 +218,14 @@ template <int NI> __device__ __forceinline__ double reduce_scatter_a(const doubl
     return keep + dppx<0x128>(send);
 }
 
+// moff(i) .. moff(i + N - 1) of N <= 64 consecutive rows: lane r works out moff(i + r) -- six vector instructions and a v_readlane per row
+// instead of seven scalar instructions per row
+template <int N> __device__ __forceinline__ void moff_batch(int i, int lane, int (&mo)[N]) {
+    const int k = i + lane, I = k >> 3;
+    const int v = (int)(__umul24((unsigned)(I + 1), (unsigned)(k - 4 * I)) << 3);  // (I + 1) (32 I + 8 a), a = k - 8 I
+#pragma unroll
+    for (int r = 0; r < N; ++r) mo[r] = __builtin_amdgcn_readlane(v, r);
+}
 // lanes <= k as a wave mask in scalar registers (k wave uniform): row masks cost no VALU compare
 __device__ __forceinline__ unsigned long long lanes_le(int k) {
     return k >= 63 ? ~0ull : (k < 0 ? 0ull : ((2ull << k) - 1ull));
@@ -268,15 +297,52 @@ struct VoxState {
     int p;
 };
 
-// bin j joins / leaves the passive flags: ONE of the four masks changes, found by two scalar branches (a select per mask costs 22 scalar
-// instructions, and a scalar instruction costs what a vector instruction costs: profiles/r05_nnls_experiments.md section 15)
+// bin j joins / leaves the passive flags: ONE bit of ONE of the four masks changes (mask 2 (j >> 7) + (j & 1), bit (j >> 1) & 63).  Written
+// out as scalar instructions: per mask an OR (AND-NOT), a compare and a conditional move -- 15 instructions; the compiler's selects
+// cost 22, and scalar branches to the one mask are rebuilt by the structuriser into four flagged blocks (measured: no better)
 __device__ __forceinline__ void set_passive(VoxState &S, int j) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) S.inP[s] |= (s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull;
+    unsigned long long t, n;
+    int k;
+    asm("s_lshr_b32 %[k], %[j], 1\n\t"
+        "s_lshl_b64 %[t], 1, %[k]\n\t"
+        "s_and_b32 %[k], %[j], 0x81\n\t"
+        "s_or_b64 %[n], %[m0], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0\n\t"
+        "s_cmov_b64 %[m0], %[n]\n\t"
+        "s_or_b64 %[n], %[m1], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 1\n\t"
+        "s_cmov_b64 %[m1], %[n]\n\t"
+        "s_or_b64 %[n], %[m2], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0x80\n\t"
+        "s_cmov_b64 %[m2], %[n]\n\t"
+        "s_or_b64 %[n], %[m3], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0x81\n\t"
+        "s_cmov_b64 %[m3], %[n]"
+        : [m0] "+s"(S.inP[0]), [m1] "+s"(S.inP[1]), [m2] "+s"(S.inP[2]), [m3] "+s"(S.inP[3]), [t] "=&s"(t), [n] "=&s"(n), [k] "=&s"(k)
+        : [j] "s"(j)
+        : "scc");
 }
 __device__ __forceinline__ void clear_passive(VoxState &S, int j) {
-#pragma unroll
-    for (int s = 0; s < kSlots; ++s) S.inP[s] &= ~((s == slot_of_bin(j)) ? (1ull << lane_of_bin(j)) : 0ull);
+    unsigned long long t, n;
+    int k;
+    asm("s_lshr_b32 %[k], %[j], 1\n\t"
+        "s_lshl_b64 %[t], 1, %[k]\n\t"
+        "s_and_b32 %[k], %[j], 0x81\n\t"
+        "s_andn2_b64 %[n], %[m0], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0\n\t"
+        "s_cmov_b64 %[m0], %[n]\n\t"
+        "s_andn2_b64 %[n], %[m1], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 1\n\t"
+        "s_cmov_b64 %[m1], %[n]\n\t"
+        "s_andn2_b64 %[n], %[m2], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0x80\n\t"
+        "s_cmov_b64 %[m2], %[n]\n\t"
+        "s_andn2_b64 %[n], %[m3], %[t]\n\t"
+        "s_cmp_eq_u32 %[k], 0x81\n\t"
+        "s_cmov_b64 %[m3], %[n]"
+        : [m0] "+s"(S.inP[0]), [m1] "+s"(S.inP[1]), [m2] "+s"(S.inP[2]), [m3] "+s"(S.inP[3]), [t] "=&s"(t), [n] "=&s"(n), [k] "=&s"(k)
+        : [j] "s"(j)
+        : "scc");
 }
 
 // ---- round 4: the dual with its LDS round trips overlapped ---------------------------------------------------
@@ -703,7 +769,7 @@ __device__ __forceinline__ void append_prepare(const double *G, const MRef &M, c
 #pragma unroll
         for (int K = 0; K <= I; ++K) rK[K] = fma(row[K], lr, rK[K]);
     }
-    ll = allreduce_a(ll);
+    ll = sum_a_uni(ll);
     // rows >= 48: row by row (lanes over the columns), four rows in flight
     double a1[kPS];    // l^T M by position
 #pragma unroll
@@ -730,9 +796,11 @@ __device__ __forceinline__ void append_prepare(const double *G, const MRef &M, c
         auto four = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             double m[4][si + 1];
+            int mo[4];
+            moff_batch<4>(i, lane, mo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rbase = moff(i + r);
+                const int rbase = mo[r];
 #pragma unroll
                 for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
             }
@@ -874,9 +942,11 @@ __device__ __forceinline__ void mt_times_q(const MRef &M, double *stg, int lane,
         auto four = [&](int i, auto T) {
             constexpr int si = decltype(T)::value;
             double m[4][si + 1];
+            int mo[4];
+            moff_batch<4>(i, lane, mo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rbase = moff(i + r);
+                const int rbase = mo[r];
 #pragma unroll
                 for (int s = 0; s <= si; ++s) m[r][s] = M.g[CK(rbase + lane + kW * s, kMSlab, 6, i + r)];
             }
@@ -1013,7 +1083,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                 // largest dual: none positive = KKT satisfied, the voxel is done.  (Tested here, in front of the instantiations of the candidate
                 // step: a return value of theirs would merge the unchanged voxel state with the one an append leaves -- 15 register moves
                 // in every outer iteration for the sake of the last.)
-                const double best = uni(allreduce_max(max1(max1(w[0], w[1]), max1(w[2], w[3]))));
+                const double best = wave_max_pos_uni(max1(max1(w[0], w[1]), max1(w[2], w[3])));
                 if (!(best > 0)) {
                     status = kDone;
                     break;
@@ -1191,12 +1261,7 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
                             // moff(i) .. moff(i + nb): lane r works out moff(i + r) -- six vector instructions for the batch and a v_readlane per
                             // row instead of seven scalar instructions per row (a scalar instruction costs what a vector instruction costs)
                             int mo[nb + 1];
-                            {
-                                const int k = i + lane, I = k >> 3;
-                                const int v = (int)(__umul24((unsigned)(I + 1), (unsigned)(k - 4 * I)) << 3);  // (I + 1) (32 I + 8 a), a = k - 8 I
-#pragma unroll
-                                for (int r = 0; r <= nb; ++r) mo[r] = __builtin_amdgcn_readlane(v, r);
-                            }
+                            moff_batch<nb + 1>(i, lane, mo);
 #pragma unroll
                             for (int r = 0; r < nb; ++r) {
                                 const int nbase = mo[r + 1];
