@@ -1025,7 +1025,16 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
         int iteration = 0, status = finite ? 1 : -2;
         const int max_it = kargs()->max_iter;  // once per voxel: read in the inner loop it is a scalar load and a wait for every LDS access in flight per iteration
         double w[kSlots];
-        double w0[kSlots] = {0, 0, 0, 0};  // A^T y of this voxel (its dual at p = 0), for the Gram-form dual of small passive sets
+        // A^T y of this voxel = B^T y: its dual at p = 0 (x = 0: no gathers, no stencil) and the start of the Gram-form dual of small passive sets
+        double w0[kSlots];
+        {
+            const double zero4[kSlots] = {0, 0, 0, 0};
+            lds_order();
+            if (lane < kBMeas) rb[lane] = yreg;
+            lds_order();
+            bt_times_h(Bl, rb, (nm + 7) & ~7, lane, w0, []() {}, zero4);
+            lds_order();
+        }
         STAMP(0);
         COUNT(0, 1);
 
@@ -1057,15 +1066,14 @@ template <bool HOOK> __device__ __forceinline__ void blk_body() {
 #else
                 const int mrows = (K->n_meas + 7) & ~7;
 #endif
-                if (kGramP > 0 && S.p > 0 && S.p <= kGramP)
-                    dual_gram_form(xbuf, ps, ld, w0, S, w);
-                else {
-                    dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, mrows, ld, yreg, S, w);
-                    if (kGramP > 0 && S.p == 0) {
+                if (S.p == 0) {  // x = 0: the dual is A^T y, worked out when the voxel was fetched
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) w0[s] = w[s];
-                    }
-                }
+                    for (int s = 0; s < kSlots; ++s) w[s] = w0[s];
+                    stage_ps(xbuf, ps, 0, ld, S.pidx);  // what the append's prefetch reads: the padding bin at every position
+                } else if (kGramP > 0 && S.p <= kGramP)
+                    dual_gram_form(xbuf, ps, ld, w0, S, w);
+                else
+                    dual_residual_form(Bl, xbuf, ps, rb, rc, K->rhb, n, mrows, ld, yreg, S, w);
                 // passive (and rejected, and non-existent) bins leave the arg-max: their dual becomes a huge negative number -- the HIGH word
                 // alone is replaced (0xffe00000: -8.99e307 or below whatever the low word holds; one select per bin instead of two for -inf)
 #pragma unroll
