@@ -607,7 +607,7 @@ __device__ __forceinline__ void dual_residual_form(const double *Bl, double *xbu
 // a fifth of the vector instructions and one or two round trips instead of eight.  A^T y is this voxel's dual at p = 0 (the residual
 // form with x = 0), kept in registers.  Same quantity in another summation order; the factor M already comes from the same G.
 #ifndef PNX_BLK_GRAMP
-#define PNX_BLK_GRAMP 20  // round 5, final kernel, C4 volume: 16 / 20 / 24: 393.7 / 385.9 / 386.2 ms and 137 / 144 / 151 GB behind the L2 (more rows of G through the L2 evict more rows of M): 20 (profiles/r05_nnls_experiments.md, sections 3, 16 and 17)
+#define PNX_BLK_GRAMP 16  // round 5, final kernel, C4 volume: 16 / 20 / 24: 393.7 / 385.9 / 386.2 ms, 137 / 144 / 151 GB behind the L2 (more rows of G through the L2 evict more rows of M), largest coefficient error of 524 288 voxels 5.1e-7 / 9.0e-7 / 6.0e-7 of the peak: 16 (profiles/r05_nnls_experiments.md, sections 3, 16 and 17)
 #endif
 constexpr int kGramP = PNX_BLK_GRAMP;
 static_assert(kGramP >= 0 && kGramP < kW && kGramP % 4 == 0, "the Gram-form dual reads positions of the first register slot only, in batches of four");
