@@ -224,7 +224,7 @@ PNX_API int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox,
  * ill-conditioned cases 2-3 % of them leave the oracle's path -- status flips at the iteration limit, coefficients off by up to
  * 1.5e-4 of the peak against the narrow plans' 1e-6 (profiles/r04_v_fuzz_nnls_wide.json: 5 of 200 cases; the listed cases are
  * the expected failures of `tests/fuzz_gpu_vs_oracle_nnls.py --wide`).  Measured on the C4 signal with 32 b-values: 3.4 M voxels/s at 300 bins, 2.7 M at
- * 384 and 1.7 M at 512 with the order-2 regulariser (8.6 M at 250: the step at 257 bins is a factor of 2.5), 8.8 M / 7.9 M
+ * 384 and 1.7 M at 512 with the order-2 regulariser (10.3 M at 250 on 2^20 voxels: the step at 257 bins is a factor of 3), 8.8 M / 7.9 M
  * without (10.5 M at 250).
  * pnx_nnls_aty_f64 (the MFMA step on its own) stays a 256-column layout and refuses a wide plan.
  */
