@@ -32,10 +32,21 @@
 //     both counters);
 //   * a rejected candidate column sets its passive flag and the dual is evaluated again -- no loop around the append, which had
 //     cost every outer iteration 128 bytes of scratch per lane: the kernel has none left.
-// What bounds it (profiles/r04_*): VALU (66 % of a SIMD at three waves) and LDS (70 %) together; every fp64 FMA of the B^T r
-// product (128 per lane and outer iteration) is needed, so the lever stays the instruction count around them.  The kernel
-// arguments are read from the kernarg segment where they are used, the LDS scratch sits below 64 KB (DS offsets as immediates),
-// phases take a fresh copy of the lane id: all three keep hoisted values out of registers the hot loops need.
+// The kernel arguments are read from the kernarg segment where they are used, the LDS scratch sits below 64 KB (DS offsets as
+// immediates), phases take a fresh copy of the lane id: all three keep hoisted values out of registers the hot loops need.
+// Round 5 (profiles/r05_nnls_experiments.md): the dual of a passive set of 1 .. 16 columns in Gram form (rows of G out of L2, A^T y
+// = B^T y once per voxel), R^T R x as one five-point stencil for the tridiagonal regularisers -- and then the measurement that a
+// SCALAR instruction costs what a vector instruction costs, both their share of all the instructions a wave issues (100 dummy
+// s_add_u32 per outer iteration: + 6.6 %, 100 v_add_u32: + 6.4 %).  What bounds the kernel is the length of a wave's instruction
+// stream, so the second half of the round took 16 % of ALL instructions out (86.2 k -> 72.1 k per voxel, 9.4 -> 10.7 M voxels/s):
+//   * the candidate step is append_prepare<NI> (reads the voxel state: arg-max bin by s_ff1 / s_min_u32, l = M g, independence test,
+//     l^T M) and ONE append_commit (lane writes, no EXEC masks, nothing to clear: x is zero behind the passive set);
+//   * the outer iteration is TWO loops: its rare ways out leave the inner one with the state untouched, so the state is loop carried
+//     along one path and updated in place (the structuriser had paid ~30 register moves per iteration for merging "unchanged" with
+//     "appended"); the test hook that forces rejections is a kernel of its own (nnls_blk_hook_kernel);
+//   * row offsets of a batch of rotation rows are worked out by the lanes (moff_batch), row masks are the previous mask shifted,
+//     passive flags change by scalar conditional moves, wave-uniform reductions end in row broadcasts, stage_bins has no branch,
+//     scalar loads are issued before LDS traffic is in flight (they share its counter).
 // One wavefront owns one voxel; waves pull voxels from an atomic queue and never meet after the basis is staged.
 #include <hip/hip_runtime.h>
 
