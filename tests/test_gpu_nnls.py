@@ -47,6 +47,39 @@ def test_matches_oracle_seeded(gpu, oracle, order):
     assert (((r["coefficients"] > 0) != (o["coefficients"] > 0)).sum(axis=1) == 0).mean() > 0.99
 
 
+@pytest.mark.parametrize("n_bins", [65, 34, 129, 201, 256])
+@pytest.mark.parametrize("order", [1, 2])
+def test_last_bin_in_every_register_slot(gpu, oracle, n_bins, order):
+    """The block kernel evaluates R^T R x of the tridiagonal regularisers as one five-point stencil with a correction at each end, and
+    the last bin sits in another register slot depending on n_bins (bin 64: slot 0, 33: slot 1, 128 / 200: slot 2, 255: slot 3; the
+    250 bins of the other tests: slot 3, their 50: slot 1): every slot against the oracle, passive sets on both sides of the
+    Gram-form threshold."""
+    from pyneapple_amd import synth
+
+    cfg = dict(synth.NNLS_CFG, reg_order=order, n_bins=n_bins)
+    _, basis, reg = synth.nnls_matrices(32, cfg)
+    assert basis.shape == (32, n_bins)
+    _, y, _ = synth.make_numpy("tri_reduced", 384, 32, sigma=0.01, seed=7 + n_bins, scale=1000.0)
+    # a third of the voxels: signals made of the first and the last bins, so that x_0 and x_{n-1} -- what the end corrections multiply --
+    # are in the solution
+    rng = np.random.default_rng(n_bins)
+    ends = np.zeros((128, n_bins))
+    ends[:, 0] = rng.uniform(100, 1000, 128)
+    ends[:, -1] = rng.uniform(100, 1000, 128)
+    ends[:, -2] = rng.uniform(0, 300, 128)
+    y[:128] = ends @ basis.T * (1 + 0.01 * rng.standard_normal((128, 32)))
+    r = gpu.nnls(basis, reg, y, 250)
+    o = oracle.nnls(basis, reg, y, 250, n_threads=8)
+    np.testing.assert_array_equal(r["status"], o["status"])
+    ok = o["status"] == 1
+    assert ok.mean() > 0.9
+    assert _scaled_err(r["coefficients"][ok], o["coefficients"][ok]).max() < 1e-6
+    np.testing.assert_allclose(r["residual"][ok], o["residual"][ok], rtol=1e-9)
+    assert (r["iters"] == o["iters"]).mean() > 0.99
+    assert (o["coefficients"][ok] > 0).sum(axis=1).max() > 16  # beyond the Gram-form dual's passive sets too
+    assert (o["coefficients"][ok][:, -1] > 0).sum() > 10 and (o["coefficients"][ok][:, 0] > 0).sum() > 10
+
+
 @pytest.mark.parametrize("n_b,n_bins,d_range", [(32, 250, (0.0008, 0.5)), (16, 50, (1e-4, 0.1)), (24, 120, (0.0008, 0.5))])
 def test_unregularised_matches_oracle(gpu, oracle, n_b, n_bins, d_range):
     """reg_order = 0, the reference's default (nnls_solver.py:37): A = B alone, rank deficient.  The QR-based kernel
