@@ -222,7 +222,7 @@ PNX_API int pnx_curvefit_batch_f32(const pnx_curvefit_opts *opts, int64_t n_vox,
  * fixtures g11_* and the oracle tests; NOT the same parity bar everywhere: a REGULARISED wide plan evaluates everything in Gram
  * form (condition number squared; the narrow plans' residual-form dual does not exist at eight bins per lane), and on random
  * ill-conditioned cases 2-3 % of them leave the oracle's path -- status flips at the iteration limit, coefficients off by up to
- * 1.5e-4 of the peak against the narrow plans' 1e-6 (profiles/r04_v_fuzz_nnls_wide.json: 5 of 200 cases; the listed cases are
+ * 1.5e-4 of the peak against the narrow plans' 1e-6 (profiles/r05_fuzz_nnls_wide.json: 7 of 200 cases; the listed cases are
  * the expected failures of `tests/fuzz_gpu_vs_oracle_nnls.py --wide`).  Measured on the C4 signal with 32 b-values: 3.4 M voxels/s at 300 bins, 2.7 M at
  * 384 and 1.7 M at 512 with the order-2 regulariser (10.3 M at 250 on 2^20 voxels: the step at 257 bins is a factor of 3), 8.8 M / 7.9 M
  * without (10.5 M at 250).
