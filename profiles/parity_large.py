@@ -3,7 +3,7 @@
 and of the C4 workload (default 131 072).  For the curve fit the voxels beyond rtol 1e-4 are characterised by their cost
 difference (a flat valley gives different parameters at the same cost).
 
-    python profiles/parity_large.py [--c3 N] [--c4 M] [--json profiles/r03_parity_large.json]
+    python profiles/parity_large.py [--c3 N] [--c4 M] [--c4-first K] [--json profiles/r03_parity_large.json]
 
 `c3()` / `c4()` are what tests/test_gpu_parity_large.py runs on a bounded sample inside the GPU suite."""
 import json
@@ -54,7 +54,7 @@ def c3(n=1 << 20, verbose=True):
     return res
 
 
-def c4(m=1 << 17, verbose=True):
+def c4(m=1 << 17, verbose=True, first=0):
     import torch
     from oracle import pnx_oracle as O
     from pyneapple_amd import api, synth
@@ -62,7 +62,7 @@ def c4(m=1 << 17, verbose=True):
     dev = torch.device("cuda", 0)
     bins, basis, reg = synth.nnls_matrices(32)
     plan = api.NnlsPlan(basis, reg, 0)
-    _, y = synth.make_torch_rows("tri_reduced", 0, m, 32, dev, sigma=0.01, scale=1000.0)
+    _, y = synth.make_torch_rows("tri_reduced", first, first + m, 32, dev, sigma=0.01, scale=1000.0)
     coeff = torch.empty((m, 250), dtype=torch.float64, device=dev); rn = torch.empty(m, dtype=torch.float64, device=dev)
     s8 = torch.empty(m, dtype=torch.int8, device=dev); it = torch.empty(m, dtype=torch.int32, device=dev)
     plan.solve_device(m, y, 250, coeff, rn, s8, it, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
@@ -80,7 +80,7 @@ def c4(m=1 << 17, verbose=True):
             "rnorm_gpu": float(rn[v]), "rnorm_oracle": float(o["residual"][v]),
             "largest_coefficient_on_a_differing_bin_rel_peak": float(max([abs(c[v, j]) for j in np.flatnonzero((c[v] > 0) != (cr[v] > 0))] + [abs(cr[v, j]) for j in np.flatnonzero((c[v] > 0) != (cr[v] > 0))] + [0.0]) / np.abs(cr[v]).max())}
            for v in differ[:16]]
-    return {"voxels_with_a_different_path": odd,"workload": "C4 NNLS 250 bins, reg_order 2, mu 0.02, 32 b-values, seed-fixed synthetic rows [0, n)", "n": m,
+    return {"voxels_with_a_different_path": odd,"workload": "C4 NNLS 250 bins, reg_order 2, mu 0.02, 32 b-values, seed-fixed synthetic rows [first, first + n)", "first": first, "n": m,
             "status_equal": float((s8.cpu().numpy() == o["status"]).mean()), "iters_equal": float((it.cpu().numpy() == o["iters"]).mean()),
             "support_equal": float((((c > 0) == (cr > 0)).all(axis=1)).mean()), "coef_err_max": float(err.max()),
             "coef_err_median": float(np.median(err)), "max_passive_set": int((c > 0).sum(axis=1).max()),
@@ -99,7 +99,7 @@ def main():
         out["curvefit"] = c3(n3)
         print("curvefit", json.dumps(out["curvefit"]), flush=True)
     if n4:
-        out["nnls"] = c4(n4)
+        out["nnls"] = c4(n4, first=int(a[a.index("--c4-first") + 1]) if "--c4-first" in a else 0)
         print("nnls", json.dumps(out["nnls"]), flush=True)
     if "--json" in a:
         with open(a[a.index("--json") + 1], "w") as fh:
